@@ -1,0 +1,622 @@
+// bf_capi.hip -- implementation of include/dcs_beamformer.h (the C-ABI).
+// Host code only; the kernels are in bf_kernels.hip.  Nothing here exits,
+// throws across the boundary, prints, or starts threads.
+
+#include "../../include/dcs_beamformer.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "bf_kernels.h"
+
+static_assert(sizeof(dcs_delay_vals) == 16, "delay_vals must be 4 x fp32 (BeamformerParameters.h:61-66)");
+
+#define DCS_TRY(expr)                          \
+    do {                                       \
+        hipError_t _e = (expr);                \
+        if (_e != hipSuccess) return (int)_e;  \
+    } while (0)
+
+namespace {
+
+constexpr uint32_t kDtSlotFloats = 4096; // time steps per tiled launch
+constexpr int kDtSlots = 8;
+
+inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
+
+bool params_ok(const dcs_bf_params *p)
+{
+    if (!p) return false;
+    if (p->nr_channels < 1 || p->nr_channels > (1 << 24)) return false; // (float)c must be exact
+    if (p->nr_stations < 1 || p->nr_beams < 1) return false;
+    if ((uint64_t)p->nr_stations * (uint64_t)p->nr_beams > 0x7fffffffull) return false;
+    if (!(p->sampling_period > 0.0f) || !std::isfinite(p->sampling_period)) return false;
+    if (p->fft_size < 1) return false;
+    const float D = p->sampling_period * (float)p->nr_channels;
+    if (!(D >= 0x1p-40f && D <= 0x1p40f)) return false; // dcs_div_const's proven range
+    return true;
+}
+
+dcs_bf_consts make_consts(const dcs_bf_params *p)
+{
+    dcs_bf_consts k;
+    // BeamformerCoefficientTest.cu:322  (SAMPLING_PERIOD*NR_CHANNELS): fp32 * int->fp32
+    volatile float D = p->sampling_period * (float)p->nr_channels;
+    volatile float y = 1.0f / D; // one IEEE fp32 divide
+    k.fDenominator = D;
+    k.fRcpDenominator = y;
+    // |fDelayN| <= |rate| * (C-1) * pi / D * (1 + 3*2^-24); keep a 1e-4 margin.
+    const double scale = (double)(p->nr_channels - 1) * 3.14159274101257324219 / (double)D;
+    k.fRotBoundScale = (float)(scale * 1.0001) ;
+    if (!(k.fRotBoundScale >= 0.0f)) k.fRotBoundScale = INFINITY;
+    k.fPad = 0.0f;
+    k.dHalfChannels = p->nr_channels / 2.0; // BeamformerCoefficientTest.cu:323
+    k.dDenominator = (double)D;
+    return k;
+}
+
+} // namespace
+
+struct dcs_bf_context {
+    dcs_bf_params p;
+    dcs_bf_consts k;
+    uint32_t n_pairs;
+    int device;
+    dcs_delay_vals *d_table[2]; // double-buffered compact table
+    int cur;                    // buffer generate reads
+    bool table_set;
+    float *d_dt;                // kDtSlots * kDtSlotFloats
+    float *h_dt;                // pinned mirror
+    hipEvent_t dt_ev[kDtSlots];
+    bool dt_used[kDtSlots];
+    int dt_next;
+    // tuning
+    int chan_per_block;
+    int tiles_per_block;
+    int nontemporal;
+    int nomath;
+};
+
+struct dcs_bf_stream {
+    dcs_bf_context *ctx;
+    hipStream_t stream;
+    hipGraphExec_t exec[2];
+    hipGraph_t graph[2];
+    float *h_dt;   // pinned, one float
+    float *d_dt;   // device, one float
+    dcs_delay_vals *h_table; // pinned staging for table updates
+    int bitwidth;
+    uint32_t c0, nc;
+    void *d_out;
+};
+
+extern "C" {
+
+const char *dcs_error_string(int status)
+{
+    switch (status) {
+    case DCS_OK: return "dcs: success";
+    case DCS_ERR_INVALID_ARGUMENT: return "dcs error: invalid argument";
+    case DCS_ERR_UNSUPPORTED: return "dcs error: this kernel does not support the requested mode";
+    case DCS_ERR_NOT_READY: return "dcs error: not ready (no delay table set)";
+    case DCS_ERR_OUT_OF_RANGE: return "dcs error: out of range";
+    case DCS_ERR_NO_DEVICE: return "dcs error: no HIP device";
+    default: break;
+    }
+    if (status > 0) return hipGetErrorString((hipError_t)status);
+    return "dcs error: unknown status";
+}
+
+int dcs_abi_version(void) { return DCS_BF_ABI_VERSION; }
+
+int dcs_bf_default_params(dcs_bf_params *p)
+{
+    if (!p) return DCS_ERR_INVALID_ARGUMENT;
+    // BeamformerParameters.h:7-17
+    p->nr_channels = 64;
+    p->nr_stations = 64;
+    p->nr_beams = 16;
+    p->nr_samples_per_channel = 256;
+    p->sampling_period = 1e-7f;
+    p->fft_size = 8192;
+    p->adc_sample_rate = 1712e6;
+    p->accumulations_before_new_coeffs = 256;
+    p->reserved = 0;
+    return DCS_OK;
+}
+
+int dcs_bf_output_bytes(const dcs_bf_params *p, int bitwidth, uint32_t nt, size_t *bytes)
+{
+    if (!params_ok(p) || !bytes) return DCS_ERR_INVALID_ARGUMENT;
+    if (bitwidth != DCS_BF_B16 && bitwidth != DCS_BF_B32) return DCS_ERR_INVALID_ARGUMENT;
+    // BeamformerCoefficientTest.cu:32-38
+    const size_t elem = bitwidth == DCS_BF_B16 ? sizeof(uint16_t) : sizeof(float);
+    *bytes = (size_t)nt * (size_t)p->nr_channels * (size_t)p->nr_stations * (size_t)p->nr_beams * 2u * elem;
+    return DCS_OK;
+}
+
+int dcs_bf_delta_times(const dcs_bf_params *p, uint64_t t0, uint32_t nt, float *dt_out)
+{
+    if (!params_ok(p) || (!dt_out && nt)) return DCS_ERR_INVALID_ARGUMENT;
+    for (uint32_t i = 0; i < nt; i++) {
+        const uint64_t t = t0 + i;
+        // BeamformerCoefficientTest.cu:299: long timeStep = t*SAMPLING_PERIOD*1e9f*FFT_SIZE;
+        // size_t -> float, three fp32 products left to right, truncation.
+        volatile float a = (float)t;
+        volatile float b = a * p->sampling_period;
+        volatile float c = b * 1e9f;
+        volatile float d = c * (float)p->fft_size;
+        if (!(d < 9.2e18f)) return DCS_ERR_OUT_OF_RANGE;
+        const long step_ns = (long)d;
+        // ts_diff(ref, ref + step): (float)sec - (float)sec == 0, then
+        // += (float)nanosec_difference / 1e9f   (BeamformerCoefficientTest.cu:14-16)
+        volatile float num = (float)step_ns;
+        volatile float q = num / 1e9f;
+        volatile float dt = 0.0f + q;
+        dt_out[i] = dt;
+    }
+    return DCS_OK;
+}
+
+int dcs_bf_simulate_input(const dcs_bf_params *p, dcs_delay_vals *out)
+{
+    if (!params_ok(p) || !out) return DCS_ERR_INVALID_ARGUMENT;
+    // BeamformerCoefficientTest.cu:185-196
+    const size_t n = (size_t)p->nr_stations * (size_t)p->nr_beams;
+    for (size_t i = 0; i < n; i++) {
+        volatile float ratio = (float)i / (float)n;
+        volatile float ramp = ratio * p->sampling_period;
+        out[i].fDelay_s = (float)((double)ramp / 3.0);
+        out[i].fDelayRate_sps = (float)2e-6;
+        volatile float inv = 1.0f - ratio;
+        volatile float ramp2 = inv * p->sampling_period;
+        out[i].fPhase_rad = (float)((double)ramp2 / 3.0);
+        out[i].fPhaseRate_radps = (float)3e-6;
+    }
+    return DCS_OK;
+}
+
+/* ---- device plumbing ---------------------------------------------------- */
+int dcs_device_count(int *count)
+{
+    if (!count) return DCS_ERR_INVALID_ARGUMENT;
+    *count = 0;
+    hipError_t e = hipGetDeviceCount(count);
+    if (e == hipErrorNoDevice) { *count = 0; return DCS_OK; }
+    return (int)e;
+}
+int dcs_device_set(int device) { return (int)hipSetDevice(device); }
+int dcs_device_synchronize(void) { return (int)hipDeviceSynchronize(); }
+int dcs_device_name(int device, char *buf, size_t buflen)
+{
+    if (!buf || buflen == 0) return DCS_ERR_INVALID_ARGUMENT;
+    hipDeviceProp_t prop;
+    DCS_TRY(hipGetDeviceProperties(&prop, device));
+    std::snprintf(buf, buflen, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+    return DCS_OK;
+}
+int dcs_malloc(void **dptr, size_t bytes)
+{
+    if (!dptr) return DCS_ERR_INVALID_ARGUMENT;
+    return (int)hipMalloc(dptr, bytes);
+}
+int dcs_free(void *dptr) { return (int)hipFree(dptr); }
+int dcs_host_alloc(void **hptr, size_t bytes)
+{
+    if (!hptr) return DCS_ERR_INVALID_ARGUMENT;
+    return (int)hipHostMalloc(hptr, bytes, hipHostMallocDefault);
+}
+int dcs_host_free(void *hptr) { return (int)hipHostFree(hptr); }
+int dcs_memcpy_htod(void *dptr, const void *hptr, size_t bytes, void *stream)
+{
+    return (int)hipMemcpyAsync(dptr, hptr, bytes, hipMemcpyHostToDevice, as_stream(stream));
+}
+int dcs_memcpy_dtoh(void *hptr, const void *dptr, size_t bytes, void *stream)
+{
+    return (int)hipMemcpyAsync(hptr, dptr, bytes, hipMemcpyDeviceToHost, as_stream(stream));
+}
+int dcs_memcpy_dtod(void *dst, const void *src, size_t bytes, void *stream)
+{
+    return (int)hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, as_stream(stream));
+}
+int dcs_memcpy2d_dtoh(void *hptr, size_t dst_pitch, const void *dptr, size_t src_pitch, size_t row_bytes,
+                      size_t nrows, void *stream)
+{
+    return (int)hipMemcpy2DAsync(hptr, dst_pitch, dptr, src_pitch, row_bytes, nrows, hipMemcpyDeviceToHost,
+                                 as_stream(stream));
+}
+int dcs_memset(void *dptr, int value, size_t bytes, void *stream)
+{
+    return (int)hipMemsetAsync(dptr, value, bytes, as_stream(stream));
+}
+int dcs_stream_create(void **stream)
+{
+    if (!stream) return DCS_ERR_INVALID_ARGUMENT;
+    hipStream_t s;
+    DCS_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    *stream = s;
+    return DCS_OK;
+}
+int dcs_stream_destroy(void *stream) { return (int)hipStreamDestroy(as_stream(stream)); }
+int dcs_stream_synchronize(void *stream) { return (int)hipStreamSynchronize(as_stream(stream)); }
+
+int dcs_event_create(void **event)
+{
+    if (!event) return DCS_ERR_INVALID_ARGUMENT;
+    hipEvent_t e;
+    DCS_TRY(hipEventCreate(&e));
+    *event = e;
+    return DCS_OK;
+}
+int dcs_event_destroy(void *event) { return (int)hipEventDestroy(reinterpret_cast<hipEvent_t>(event)); }
+int dcs_event_record(void *event, void *stream)
+{
+    return (int)hipEventRecord(reinterpret_cast<hipEvent_t>(event), as_stream(stream));
+}
+int dcs_event_synchronize(void *event) { return (int)hipEventSynchronize(reinterpret_cast<hipEvent_t>(event)); }
+int dcs_event_elapsed_ms(void *start, void *stop, float *ms)
+{
+    if (!ms) return DCS_ERR_INVALID_ARGUMENT;
+    return (int)hipEventElapsedTime(ms, reinterpret_cast<hipEvent_t>(start), reinterpret_cast<hipEvent_t>(stop));
+}
+
+/* ---- context ------------------------------------------------------------ */
+int dcs_bf_create(const dcs_bf_params *p, dcs_bf_context **out)
+{
+    if (!out) return DCS_ERR_INVALID_ARGUMENT;
+    *out = nullptr;
+    if (!params_ok(p)) return DCS_ERR_INVALID_ARGUMENT;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return DCS_ERR_NO_DEVICE;
+    dcs_bf_context *c = new (std::nothrow) dcs_bf_context();
+    if (!c) return (int)hipErrorOutOfMemory;
+    std::memset(c, 0, sizeof(*c));
+    c->p = *p;
+    c->k = make_consts(p);
+    c->n_pairs = (uint32_t)p->nr_stations * (uint32_t)p->nr_beams;
+    c->nontemporal = -1;
+    int st = DCS_OK;
+    do {
+        if ((st = (int)hipGetDevice(&c->device)) != 0) break;
+        const size_t tb = (size_t)c->n_pairs * sizeof(dcs_delay_vals);
+        if ((st = (int)hipMalloc((void **)&c->d_table[0], tb)) != 0) break;
+        if ((st = (int)hipMalloc((void **)&c->d_table[1], tb)) != 0) break;
+        const size_t db = (size_t)kDtSlots * kDtSlotFloats * sizeof(float);
+        if ((st = (int)hipMalloc((void **)&c->d_dt, db)) != 0) break;
+        if ((st = (int)hipHostMalloc((void **)&c->h_dt, db, hipHostMallocDefault)) != 0) break;
+        for (int i = 0; i < kDtSlots && st == 0; i++) st = (int)hipEventCreateWithFlags(&c->dt_ev[i], hipEventDisableTiming);
+    } while (0);
+    if (st != 0) {
+        dcs_bf_destroy(c);
+        return st;
+    }
+    *out = c;
+    return DCS_OK;
+}
+
+int dcs_bf_destroy(dcs_bf_context *c)
+{
+    if (!c) return DCS_OK;
+    (void)hipFree(c->d_table[0]);
+    (void)hipFree(c->d_table[1]);
+    (void)hipFree(c->d_dt);
+    if (c->h_dt) (void)hipHostFree(c->h_dt);
+    for (int i = 0; i < kDtSlots; i++)
+        if (c->dt_ev[i]) (void)hipEventDestroy(c->dt_ev[i]);
+    delete c;
+    return DCS_OK;
+}
+
+int dcs_bf_upload_delays(dcs_bf_context *c, const dcs_delay_vals *table, void *stream)
+{
+    if (!c || !table) return DCS_ERR_INVALID_ARGUMENT;
+    const int nxt = c->table_set ? (c->cur ^ 1) : c->cur;
+    DCS_TRY(hipMemcpyAsync(c->d_table[nxt], table, (size_t)c->n_pairs * sizeof(dcs_delay_vals),
+                           hipMemcpyHostToDevice, as_stream(stream)));
+    c->cur = nxt;
+    c->table_set = true;
+    return DCS_OK;
+}
+
+int dcs_bf_set_delays_from_global(dcs_bf_context *c, const void *d_global, uint32_t nb_total,
+                                  uint32_t beam_offset, void *stream)
+{
+    if (!c || !d_global) return DCS_ERR_INVALID_ARGUMENT;
+    if ((uint64_t)beam_offset + (uint64_t)c->p.nr_beams > nb_total) return DCS_ERR_OUT_OF_RANGE;
+    if ((reinterpret_cast<uintptr_t>(d_global) & 15u) != 0) return DCS_ERR_INVALID_ARGUMENT;
+    const int nxt = c->table_set ? (c->cur ^ 1) : c->cur;
+    DCS_TRY(bf_launch_gather_beams(c->d_table[nxt], static_cast<const dcs_delay_vals *>(d_global),
+                                   (uint32_t)c->p.nr_stations, (uint32_t)c->p.nr_beams, nb_total, beam_offset,
+                                   as_stream(stream)));
+    c->cur = nxt;
+    c->table_set = true;
+    return DCS_OK;
+}
+
+int dcs_bf_set_tuning(dcs_bf_context *c, int chan_per_block, int tiles_per_block, int nontemporal)
+{
+    if (!c) return DCS_ERR_INVALID_ARGUMENT;
+    const int nomath = (tiles_per_block & 0x100) ? 1 : 0; // probe: stores only
+    tiles_per_block &= 0xff;
+    if (chan_per_block < 0 || chan_per_block > (1 << 24)) return DCS_ERR_INVALID_ARGUMENT;
+    if (tiles_per_block != 0 && tiles_per_block != 1 && tiles_per_block != 2 && tiles_per_block != 4)
+        return DCS_ERR_INVALID_ARGUMENT;
+    if (nontemporal < -1 || nontemporal > 1) return DCS_ERR_INVALID_ARGUMENT;
+    c->chan_per_block = chan_per_block;
+    c->tiles_per_block = tiles_per_block;
+    c->nontemporal = nontemporal;
+    c->nomath = nomath;
+    return DCS_OK;
+}
+
+namespace {
+
+// Defaults: see DESIGN.md "launch geometry".
+void pick_geometry(const dcs_bf_context *c, bool out16, uint32_t nc, uint32_t nt, int *tpb, uint32_t *cpb, bool *ntstore)
+{
+    *tpb = c->tiles_per_block ? c->tiles_per_block : 1;
+    *ntstore = c->nontemporal < 0 ? true : c->nontemporal != 0;
+    if (c->chan_per_block) {
+        *cpb = (uint32_t)c->chan_per_block;
+        return;
+    }
+    // Enough workgroups to fill 256 CUs x 8 several times over, but no fewer
+    // than 16 channels per wave so the per-workgroup fp64 set-up stays < 5 %.
+    const uint32_t ppl = out16 ? 4u : 2u;
+    const uint32_t pairs_per_block = 64u * ppl * (uint32_t)*tpb;
+    const uint64_t tile_groups = (c->n_pairs + pairs_per_block - 1) / pairs_per_block;
+    const uint32_t rows = 4u / (uint32_t)*tpb;
+    uint32_t cpb_v = 64u * rows; // 64 channels per wave
+    while (cpb_v > 16u * rows && tile_groups * ((nc + cpb_v - 1) / cpb_v) * nt < 8192u) cpb_v >>= 1;
+    *cpb = cpb_v;
+}
+
+int launch_tiled(dcs_bf_context *c, bool out16, const float *dt_dev, float dt0, uint32_t nt, uint32_t c0,
+                 uint32_t nc, void *d_out, hipStream_t stream)
+{
+    bf_tiled_args a;
+    std::memset(&a, 0, sizeof(a));
+    a.delays = c->d_table[c->cur];
+    a.out = d_out;
+    a.dt_dev = dt_dev;
+    a.dt0 = dt0;
+    a.n_pairs = c->n_pairs;
+    a.c0 = c0;
+    a.nc = nc;
+    a.nt = nt;
+    a.k = c->k;
+    int tpb;
+    uint32_t cpb;
+    bool ntstore;
+    pick_geometry(c, out16, nc, nt, &tpb, &cpb, &ntstore);
+    a.chan_per_block = cpb;
+    return (int)bf_launch_tiled(a, out16, tpb | (c->nomath ? 0x100 : 0), ntstore, stream);
+}
+
+// Stage dt[t0..t0+n) through a pinned slot into device memory on `stream`.
+int stage_dt(dcs_bf_context *c, uint64_t t0, uint32_t n, hipStream_t stream, const float **dt_dev)
+{
+    const int slot = c->dt_next;
+    c->dt_next = (c->dt_next + 1) % kDtSlots;
+    if (c->dt_used[slot]) DCS_TRY(hipEventSynchronize(c->dt_ev[slot])); // slot still in flight?
+    float *h = c->h_dt + (size_t)slot * kDtSlotFloats;
+    float *d = c->d_dt + (size_t)slot * kDtSlotFloats;
+    int st = dcs_bf_delta_times(&c->p, t0, n, h);
+    if (st != DCS_OK) return st;
+    DCS_TRY(hipMemcpyAsync(d, h, (size_t)n * sizeof(float), hipMemcpyHostToDevice, stream));
+    DCS_TRY(hipEventRecord(c->dt_ev[slot], stream));
+    c->dt_used[slot] = true;
+    *dt_dev = d;
+    return DCS_OK;
+}
+
+} // namespace
+
+int dcs_bf_generate_slab(dcs_bf_context *c, int bitwidth, uint64_t t0, uint32_t nt, uint32_t c0, uint32_t nc,
+                         void *d_out, size_t out_bytes, void *stream)
+{
+    if (!c || (!d_out && nt && nc)) return DCS_ERR_INVALID_ARGUMENT;
+    if (bitwidth != DCS_BF_B16 && bitwidth != DCS_BF_B32) return DCS_ERR_INVALID_ARGUMENT;
+    if (!c->table_set) return DCS_ERR_NOT_READY;
+    if ((uint64_t)c0 + nc > (uint64_t)c->p.nr_channels) return DCS_ERR_OUT_OF_RANGE;
+    const bool out16 = bitwidth == DCS_BF_B16;
+    const size_t eb = out16 ? 4 : 8;
+    const size_t step_bytes = (size_t)nc * c->n_pairs * eb;
+    if (out_bytes < step_bytes * nt) return DCS_ERR_INVALID_ARGUMENT;
+    hipStream_t s = as_stream(stream);
+    for (uint32_t done = 0; done < nt;) {
+        const uint32_t n = (nt - done) < kDtSlotFloats ? (nt - done) : kDtSlotFloats;
+        char *dst = static_cast<char *>(d_out) + (size_t)done * step_bytes;
+        int st;
+        if (n == 1) {
+            float dt;
+            if ((st = dcs_bf_delta_times(&c->p, t0 + done, 1, &dt)) != DCS_OK) return st;
+            st = launch_tiled(c, out16, nullptr, dt, 1, c0, nc, dst, s);
+        } else {
+            const float *dt_dev = nullptr;
+            if ((st = stage_dt(c, t0 + done, n, s, &dt_dev)) != DCS_OK) return st;
+            st = launch_tiled(c, out16, dt_dev, 0.0f, n, c0, nc, dst, s);
+        }
+        if (st != DCS_OK) return st;
+        done += n;
+    }
+    return DCS_OK;
+}
+
+int dcs_bf_generate(dcs_bf_context *c, int kernel, int bitwidth, uint64_t t0, uint32_t nt, void *d_out,
+                    size_t out_bytes, void *stream)
+{
+    if (!c) return DCS_ERR_INVALID_ARGUMENT;
+    if (bitwidth != DCS_BF_B16 && bitwidth != DCS_BF_B32) return DCS_ERR_INVALID_ARGUMENT;
+    // BeamformerCoefficientTest.cu:40-50 (the reference throws)
+    if (kernel == DCS_BF_COMBINED_COEFF_GEN_AND_BEAMFORMER_SINGLE_CHANNEL) return DCS_ERR_UNSUPPORTED;
+    if (kernel == DCS_BF_NAIVE && bitwidth == DCS_BF_B16) return DCS_ERR_UNSUPPORTED;
+    if (kernel != DCS_BF_NAIVE && kernel != DCS_BF_MULTIPLE_CHANNELS &&
+        kernel != DCS_BF_MULTIPLE_CHANNELS_AND_TIMESTAMPS)
+        return DCS_ERR_INVALID_ARGUMENT;
+    if (!d_out && nt) return DCS_ERR_INVALID_ARGUMENT;
+    if (!c->table_set) return DCS_ERR_NOT_READY;
+    const uint32_t C = (uint32_t)c->p.nr_channels;
+    if (kernel == DCS_BF_MULTIPLE_CHANNELS_AND_TIMESTAMPS)
+        return dcs_bf_generate_slab(c, bitwidth, t0, nt, 0, C, d_out, out_bytes, stream);
+
+    const bool out16 = bitwidth == DCS_BF_B16;
+    const size_t step_bytes = (size_t)C * c->n_pairs * (out16 ? 4 : 8);
+    if (out_bytes < step_bytes * nt) return DCS_ERR_INVALID_ARGUMENT;
+    hipStream_t s = as_stream(stream);
+    // host time loop, one launch per time step: BeamformerCoefficientTest.cu:230-250
+    for (uint32_t i = 0; i < nt; i++) {
+        float dt;
+        int st = dcs_bf_delta_times(&c->p, t0 + i, 1, &dt);
+        if (st != DCS_OK) return st;
+        char *dst = static_cast<char *>(d_out) + (size_t)i * step_bytes;
+        if (kernel == DCS_BF_NAIVE) {
+            bf_naive_args a;
+            std::memset(&a, 0, sizeof(a));
+            a.delays = c->d_table[c->cur];
+            a.out = reinterpret_cast<float *>(dst);
+            a.dt = dt;
+            a.n_pairs = c->n_pairs;
+            a.c0 = 0;
+            a.nc = C;
+            a.k = c->k;
+            st = (int)bf_launch_naive(a, s);
+        } else {
+            st = launch_tiled(c, out16, nullptr, dt, 1, 0, C, dst, s);
+        }
+        if (st != DCS_OK) return st;
+    }
+    return DCS_OK;
+}
+
+int dcs_bf_gpu_utilisation(const dcs_bf_params *p, float kernel_ms, float out[2])
+{
+    if (!params_ok(p) || !out) return DCS_ERR_INVALID_ARGUMENT;
+    // BeamformerCoefficientTest.cu:426-430,447-448
+    const float fRateOfFFTs_Hz = ((float)p->adc_sample_rate) / ((float)p->fft_size);
+    const float fTransferTimePerPacket_s = 1 / fRateOfFFTs_Hz;
+    float single = (kernel_ms / 1000.0) / (p->nr_samples_per_channel * fTransferTimePerPacket_s);
+    float multiple = single / ((float)p->accumulations_before_new_coeffs);
+    single *= 4;
+    multiple *= 4;
+    out[0] = single;
+    out[1] = multiple;
+    return DCS_OK;
+}
+
+/* ---- streaming ---------------------------------------------------------- */
+int dcs_bf_stream_begin(dcs_bf_context *c, int bitwidth, uint32_t c0, uint32_t nc, void *d_out, size_t out_bytes,
+                        void *stream, dcs_bf_stream **out)
+{
+    if (!c || !out || !d_out) return DCS_ERR_INVALID_ARGUMENT;
+    *out = nullptr;
+    if (bitwidth != DCS_BF_B16 && bitwidth != DCS_BF_B32) return DCS_ERR_INVALID_ARGUMENT;
+    if (!c->table_set) return DCS_ERR_NOT_READY;
+    if ((uint64_t)c0 + nc > (uint64_t)c->p.nr_channels || nc == 0) return DCS_ERR_OUT_OF_RANGE;
+    const bool out16 = bitwidth == DCS_BF_B16;
+    if (out_bytes < (size_t)nc * c->n_pairs * (out16 ? 4 : 8)) return DCS_ERR_INVALID_ARGUMENT;
+    if (stream == nullptr) return DCS_ERR_INVALID_ARGUMENT; // the null stream cannot be captured
+
+    dcs_bf_stream *s = new (std::nothrow) dcs_bf_stream();
+    if (!s) return (int)hipErrorOutOfMemory;
+    std::memset(s, 0, sizeof(*s));
+    s->ctx = c;
+    s->stream = as_stream(stream);
+    s->bitwidth = bitwidth;
+    s->c0 = c0;
+    s->nc = nc;
+    s->d_out = d_out;
+    int st = DCS_OK;
+    do {
+        if ((st = (int)hipHostMalloc((void **)&s->h_dt, sizeof(float), hipHostMallocDefault)) != 0) break;
+        if ((st = (int)hipMalloc((void **)&s->d_dt, sizeof(float))) != 0) break;
+        if ((st = (int)hipHostMalloc((void **)&s->h_table, (size_t)c->n_pairs * sizeof(dcs_delay_vals),
+                                     hipHostMallocDefault)) != 0)
+            break;
+        *s->h_dt = 0.0f;
+        // one graph per table buffer: {H2D dt scalar -> generate one time step}
+        const int saved_cur = c->cur;
+        for (int b = 0; b < 2 && st == 0; b++) {
+            c->cur = b;
+            if ((st = (int)hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal)) != 0) break;
+            st = (int)hipMemcpyAsync(s->d_dt, s->h_dt, sizeof(float), hipMemcpyHostToDevice, s->stream);
+            if (st == 0) st = launch_tiled(c, out16, s->d_dt, 0.0f, 1, c0, nc, d_out, s->stream);
+            hipGraph_t g = nullptr;
+            const int st_end = (int)hipStreamEndCapture(s->stream, &g);
+            if (st == 0) st = st_end;
+            if (st != 0) {
+                if (g) (void)hipGraphDestroy(g);
+                break;
+            }
+            s->graph[b] = g;
+            st = (int)hipGraphInstantiate(&s->exec[b], g, nullptr, nullptr, 0);
+        }
+        c->cur = saved_cur;
+    } while (0);
+    if (st != 0) {
+        dcs_bf_stream_end(s);
+        return st;
+    }
+    *out = s;
+    return DCS_OK;
+}
+
+int dcs_bf_stream_tick(dcs_bf_stream *s, uint64_t t, const dcs_delay_vals *new_table)
+{
+    if (!s) return DCS_ERR_INVALID_ARGUMENT;
+    dcs_bf_context *c = s->ctx;
+    float dt;
+    int st = dcs_bf_delta_times(&c->p, t, 1, &dt);
+    if (st != DCS_OK) return st;
+    if (new_table) {
+        // The idle buffer is not read by any launch still queued for the
+        // current one; the copy is ordered on the same stream before the
+        // graph that reads it.  h_table is reused: wait for the previous copy.
+        DCS_TRY(hipStreamSynchronize(s->stream));
+        std::memcpy(s->h_table, new_table, (size_t)c->n_pairs * sizeof(dcs_delay_vals));
+        const int nxt = c->cur ^ 1;
+        DCS_TRY(hipMemcpyAsync(c->d_table[nxt], s->h_table, (size_t)c->n_pairs * sizeof(dcs_delay_vals),
+                               hipMemcpyHostToDevice, s->stream));
+        c->cur = nxt;
+    } else {
+        // *h_dt is read by the graph's memcpy node when it executes: the
+        // previous replay must have consumed it before it is overwritten.
+        DCS_TRY(hipStreamSynchronize(s->stream));
+    }
+    *s->h_dt = dt;
+    return (int)hipGraphLaunch(s->exec[c->cur], s->stream);
+}
+
+int dcs_bf_stream_end(dcs_bf_stream *s)
+{
+    if (!s) return DCS_OK;
+    if (s->stream) (void)hipStreamSynchronize(s->stream);
+    for (int b = 0; b < 2; b++) {
+        if (s->exec[b]) (void)hipGraphExecDestroy(s->exec[b]);
+        if (s->graph[b]) (void)hipGraphDestroy(s->graph[b]);
+    }
+    if (s->h_dt) (void)hipHostFree(s->h_dt);
+    if (s->d_dt) (void)hipFree(s->d_dt);
+    if (s->h_table) (void)hipHostFree(s->h_table);
+    delete s;
+    return DCS_OK;
+}
+
+/* ---- probes ------------------------------------------------------------- */
+int dcs_probe_sincos(int which, const float *d_x, size_t n, float *d_sin, float *d_cos, void *stream)
+{
+    if (which < 0 || which > 2 || (n && (!d_x || !d_sin || !d_cos))) return DCS_ERR_INVALID_ARGUMENT;
+    return (int)bf_launch_probe_sincos(which, d_x, n, d_sin, d_cos, as_stream(stream));
+}
+
+int dcs_probe_fill(void *d_out, size_t bytes, int nontemporal, void *stream)
+{
+    if (!d_out && bytes) return DCS_ERR_INVALID_ARGUMENT;
+    return (int)bf_launch_probe_fill(d_out, bytes, nontemporal != 0, as_stream(stream));
+}
+
+} // extern "C"

@@ -1,0 +1,51 @@
+// bf_kernels.h -- host-callable launchers of the gfx950 kernels in
+// bf_kernels.hip (internal to libdcs_beamformer.so; the public boundary is
+// include/dcs_beamformer.h).
+#ifndef DCS_BF_KERNELS_H
+#define DCS_BF_KERNELS_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "bf_math.h"
+
+// One tiled launch: time steps [0, nt) x channels [c0, c0+nc) x all pairs.
+struct bf_tiled_args {
+    const dcs_delay_vals *delays; // compact table [n_pairs]
+    void *out;                    // [nt][nc][n_pairs] of {re,im} (fp32 pair or half2)
+    const float *dt_dev;          // fDeltaTime per time step (device), or nullptr
+    float dt0;                    // used when dt_dev == nullptr (nt must be 1)
+    uint32_t n_pairs;
+    uint32_t c0, nc;              // channel slab
+    uint32_t nt;
+    uint32_t chan_per_block;      // channels a workgroup walks
+    uint32_t n_tile_groups;       // ceil(n_pairs / pairs per workgroup)
+    uint32_t n_cblocks;           // ceil(nc / chan_per_block)
+    dcs_bf_consts k;
+};
+
+// tiles_per_block in {1,2,4}; out16: packed half2 output; nontemporal: nt stores.
+hipError_t bf_launch_tiled(const bf_tiled_args &a, bool out16, int tiles_per_block,
+                           bool nontemporal, hipStream_t stream);
+
+// One coefficient per lane, one time step (reference kernel a1's shape).
+struct bf_naive_args {
+    const dcs_delay_vals *delays;
+    float *out; // [nc][n_pairs][2]
+    float dt;
+    uint32_t n_pairs;
+    uint32_t c0, nc;
+    dcs_bf_consts k;
+};
+hipError_t bf_launch_naive(const bf_naive_args &a, hipStream_t stream);
+
+// local[a][b] = global[a][beam_offset + b]
+hipError_t bf_launch_gather_beams(dcs_delay_vals *local, const dcs_delay_vals *global,
+                                  uint32_t n_ant, uint32_t n_beams_local, uint32_t n_beams_total,
+                                  uint32_t beam_offset, hipStream_t stream);
+
+hipError_t bf_launch_probe_sincos(int which, const float *x, size_t n, float *s, float *c,
+                                  hipStream_t stream);
+hipError_t bf_launch_probe_fill(void *out, size_t bytes, bool nontemporal, hipStream_t stream);
+
+#endif

@@ -1,0 +1,384 @@
+// bf_kernels.hip -- gfx950 (MI355X, CDNA4) kernels of the steering-coefficient
+// generator.  Written for 64-wide wavefronts; no other target is supported.
+//
+// What is computed (reference: beamformer_coefficient_generator/
+// BeamformerCoefficientTest.cu:319-333, the CPU verifier -- NOT the reference's
+// device kernels, whose fp32 shortcuts differ from it by ~1e-5):
+//   for t, c, (a,b):  out[t][c][a][b] = (cos, sin)(fRotation(delay_vals[a][b], dt[t], c))
+//
+// Shape of the work: 8 bytes written per coefficient (4 for the fp16 form),
+// 16 bytes read per (antenna,beam) per time step -> HBM-write bound.  The
+// design follows from that:
+//   * a lane owns PPL adjacent (antenna,beam) pairs (2 for fp32, 4 for fp16), so
+//     every store is one 16-byte global_store_dwordx4 and a wave writes 1 KiB
+//     contiguous per channel (whole 128-byte lines, no read-for-ownership);
+//   * a workgroup (4 waves) owns `tiles_per_block` such 1-KiB tiles x a slab of
+//     channels; the channel-independent terms of each pair (one fp64 chain) are
+//     computed once per workgroup and staged in LDS, then held in 2*PPL VGPRs
+//     for the whole channel walk;
+//   * the per-channel work is ~35 fp32 VALU operations per coefficient (three
+//     roundings of fDelayN with a 5-op exact divide, one add, a 25-op sincos),
+//     no divide sequence, no transcendental unit, no double precision;
+//   * 64-bit addressing throughout (16 GiB per time step at 64x1024x32768).
+// Pairs whose arguments leave the fast path's proven range take a wave-uniform
+// slow branch (IEEE divide + fp64 sincos) with the same rounding behaviour.
+
+#include "bf_kernels.h"
+
+#include <hip/hip_runtime.h>
+
+namespace {
+
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+typedef float floatx2 __attribute__((ext_vector_type(2)));
+typedef uint32_t uintx4 __attribute__((ext_vector_type(4)));
+typedef _Float16 halfx2 __attribute__((ext_vector_type(2)));
+
+constexpr int kBlock = 256; // 4 waves of 64
+
+template <bool NT, typename T>
+__device__ __forceinline__ void store_global(T *p, const T v)
+{
+    if constexpr (NT)
+        __builtin_nontemporal_store(v, p);
+    else
+        *p = v;
+}
+
+// (cos, sin) of one coefficient, fast path (bf_math.h; swept exhaustively).
+__device__ __forceinline__ void coeff_fast(const float fRate, const float fPhase0, const float fChan,
+                                           const float D, const float y, float &re, float &im)
+{
+    const float rot = dcs_rotation(fRate, fPhase0, fChan, D, y);
+    dcs_sincos_fast(rot, &im, &re);
+}
+
+// Slow path: hardware-sequence IEEE divide and fp64 sincos rounded once to
+// fp32, i.e. the verifier's own definition (BeamformerCoefficientTest.cu:327-328).
+__device__ __noinline__ void coeff_slow(const float fRate, const float fPhase0, const float fChan,
+                                        const float D, float &re, float &im)
+{
+    const float rot = dcs_rotation_ieee(fRate, fPhase0, fChan, D);
+    double s, c;
+    sincos((double)rot, &s, &c);
+    re = (float)c;
+    im = (float)s;
+}
+
+__device__ __forceinline__ uint32_t pack_half2(const float re, const float im)
+{
+    // v_cvt_f16_f32 rounds to nearest even (default mode) == __floats2half2_rn
+    // (reference BeamformerKernels.cu:113,182); .x = re (low half), .y = im.
+    halfx2 h;
+    h.x = (_Float16)re;
+    h.y = (_Float16)im;
+    return __builtin_bit_cast(uint32_t, h);
+}
+
+// ---------------------------------------------------------------------------
+// Tiled generator.
+//   OUT16   : packed half2 output (4 pairs per lane) instead of fp32 (2 pairs)
+//   TPB     : 1-KiB tiles per workgroup (1, 2, 4); the 4 waves are arranged as
+//             TPB tile columns x 4/TPB channel rows
+//   NT      : nontemporal stores
+//   ALIGNED : n_pairs % PPL == 0 -> 16-byte stores; otherwise per-pair stores
+//   NOMATH  : addressing/stores only (probe: the store ceiling of this shape)
+// ---------------------------------------------------------------------------
+template <bool OUT16, int TPB, bool NT, bool ALIGNED, bool NOMATH>
+__global__ void __launch_bounds__(kBlock) bf_tiled_kernel(const bf_tiled_args a)
+{
+    constexpr int PPL = OUT16 ? 4 : 2;
+    constexpr int TILE = 64 * PPL;
+    constexpr int ROWS = 4 / TPB;
+    constexpr uint32_t EB = OUT16 ? 4u : 8u; // bytes per coefficient
+
+    __shared__ __attribute__((aligned(16))) float s_terms[TPB * TILE * 2]; // {fRateTerm, fPhase0}
+
+    // workgroup -> (tile group, channel block, time step); tile group fastest so
+    // that concurrently resident workgroups cover one channel row end to end.
+    const uint32_t bid = blockIdx.x;
+    const uint32_t tg = bid % a.n_tile_groups;
+    const uint32_t rest = bid / a.n_tile_groups;
+    const uint32_t cb = rest % a.n_cblocks;
+    const uint32_t t = rest / a.n_cblocks;
+
+    const float dt = a.dt_dev ? a.dt_dev[t] : a.dt0;
+    const uint32_t pair_base = tg * (uint32_t)(TPB * TILE);
+
+    // ---- stage the channel-independent terms of this workgroup's pairs in LDS
+    for (uint32_t i = threadIdx.x; i < (uint32_t)(TPB * TILE); i += kBlock) {
+        const uint32_t p = pair_base + i;
+        float fRate = 0.0f, fPhase0 = 0.0f;
+        if (p < a.n_pairs) {
+            const floatx4 raw = *reinterpret_cast<const floatx4 *>(&a.delays[p]);
+            dcs_delay_vals d;
+            d.fDelay_s = raw.x;
+            d.fDelayRate_sps = raw.y;
+            d.fPhase_rad = raw.z;
+            d.fPhaseRate_radps = raw.w;
+            dcs_pair_terms(d, dt, a.k.dHalfChannels, a.k.dDenominator, &fRate, &fPhase0);
+        }
+        *reinterpret_cast<floatx2 *>(&s_terms[2 * i]) = floatx2{fRate, fPhase0};
+    }
+    __syncthreads();
+
+    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t tile = wave % TPB;
+    const uint32_t row = wave / TPB;
+    const uint32_t li = tile * TILE + lane * PPL;
+    const uint32_t p0 = pair_base + li;
+
+    float fRate[PPL], fPhase0[PPL];
+    bool fast = true;
+#pragma unroll
+    for (int j = 0; j < PPL; j += 2) {
+        const floatx4 v = *reinterpret_cast<const floatx4 *>(&s_terms[2 * (li + j)]);
+        fRate[j] = v.x;
+        fPhase0[j] = v.y;
+        fRate[j + 1] = v.z;
+        fPhase0[j + 1] = v.w;
+    }
+#pragma unroll
+    for (int j = 0; j < PPL; j++) fast = fast && dcs_pair_is_fast(fRate[j], fPhase0[j], a.k.fRotBoundScale);
+    const bool wave_slow = __builtin_amdgcn_ballot_w64(!fast) != 0ull;
+
+    const uint32_t cbeg = cb * a.chan_per_block;
+    const uint32_t cend = min(cbeg + a.chan_per_block, a.nc);
+    if (p0 >= a.n_pairs) return; // after the barrier; whole lane is past the table
+
+    const float D = a.k.fDenominator, y = a.k.fRcpDenominator;
+    const uint64_t row_bytes = (uint64_t)a.n_pairs * EB;
+    char *dst = reinterpret_cast<char *>(a.out) +
+                ((uint64_t)t * a.nc + (cbeg + row)) * row_bytes + (uint64_t)p0 * EB;
+    const uint64_t step = (uint64_t)ROWS * row_bytes;
+
+    auto emit = [&](const float (&re)[PPL], const float (&im)[PPL]) {
+        if constexpr (ALIGNED) {
+            if constexpr (OUT16) {
+                uintx4 v;
+                v.x = pack_half2(re[0], im[0]);
+                v.y = pack_half2(re[1], im[1]);
+                v.z = pack_half2(re[2], im[2]);
+                v.w = pack_half2(re[3], im[3]);
+                store_global<NT>(reinterpret_cast<uintx4 *>(dst), v);
+            } else {
+                store_global<NT>(reinterpret_cast<floatx4 *>(dst), floatx4{re[0], im[0], re[1], im[1]});
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < PPL; j++) {
+                if (p0 + j < a.n_pairs) {
+                    if constexpr (OUT16)
+                        store_global<NT>(reinterpret_cast<uint32_t *>(dst) + j, pack_half2(re[j], im[j]));
+                    else
+                        store_global<NT>(reinterpret_cast<floatx2 *>(dst) + j, floatx2{re[j], im[j]});
+                }
+            }
+        }
+    };
+
+    if constexpr (NOMATH) {
+        float re[PPL], im[PPL];
+#pragma unroll
+        for (int j = 0; j < PPL; j++) {
+            re[j] = fRate[j];
+            im[j] = fPhase0[j];
+        }
+        for (uint32_t c = cbeg + row; c < cend; c += ROWS) {
+            emit(re, im);
+            dst += step;
+        }
+        return;
+    }
+
+    if (!wave_slow) {
+#pragma unroll 2
+        for (uint32_t c = cbeg + row; c < cend; c += ROWS) {
+            const float fChan = (float)(a.c0 + c);
+            float re[PPL], im[PPL];
+#pragma unroll
+            for (int j = 0; j < PPL; j++) coeff_fast(fRate[j], fPhase0[j], fChan, D, y, re[j], im[j]);
+            emit(re, im);
+            dst += step;
+        }
+    } else {
+        for (uint32_t c = cbeg + row; c < cend; c += ROWS) {
+            const float fChan = (float)(a.c0 + c);
+            float re[PPL], im[PPL];
+#pragma unroll 1
+            for (int j = 0; j < PPL; j++) coeff_slow(fRate[j], fPhase0[j], fChan, D, re[j], im[j]);
+            emit(re, im);
+            dst += step;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// One coefficient per lane (the launch shape of the reference's
+// calculate_beamweights_naive, BeamformerKernels.cu:7-52): every lane redoes the
+// per-pair terms.  grid = (ceil(n_pairs/256), min(nc, 65535)).
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock) bf_naive_kernel(const bf_naive_args a)
+{
+    const uint32_t p = blockIdx.x * kBlock + threadIdx.x;
+    if (p >= a.n_pairs) return;
+    const floatx4 raw = *reinterpret_cast<const floatx4 *>(&a.delays[p]);
+    dcs_delay_vals d;
+    d.fDelay_s = raw.x;
+    d.fDelayRate_sps = raw.y;
+    d.fPhase_rad = raw.z;
+    d.fPhaseRate_radps = raw.w;
+    float fRate, fPhase0;
+    dcs_pair_terms(d, a.dt, a.k.dHalfChannels, a.k.dDenominator, &fRate, &fPhase0);
+    const bool fast = dcs_pair_is_fast(fRate, fPhase0, a.k.fRotBoundScale);
+    for (uint32_t c = blockIdx.y; c < a.nc; c += gridDim.y) {
+        const float fChan = (float)(a.c0 + c);
+        float re, im;
+        if (fast)
+            coeff_fast(fRate, fPhase0, fChan, a.k.fDenominator, a.k.fRcpDenominator, re, im);
+        else
+            coeff_slow(fRate, fPhase0, fChan, a.k.fDenominator, re, im);
+        floatx2 *dst = reinterpret_cast<floatx2 *>(a.out) + ((uint64_t)c * a.n_pairs + p);
+        *dst = floatx2{re, im};
+    }
+}
+
+__global__ void __launch_bounds__(kBlock) bf_gather_beams_kernel(dcs_delay_vals *local,
+                                                                 const dcs_delay_vals *global,
+                                                                 uint32_t n_ant, uint32_t nb_local,
+                                                                 uint32_t nb_total, uint32_t beam_offset)
+{
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n_ant * nb_local) return;
+    const uint32_t ant = i / nb_local, b = i - ant * nb_local;
+    const floatx4 v = *reinterpret_cast<const floatx4 *>(&global[(uint64_t)ant * nb_total + beam_offset + b]);
+    *reinterpret_cast<floatx4 *>(&local[i]) = v;
+}
+
+__global__ void __launch_bounds__(kBlock) bf_probe_sincos_kernel(int which, const float *x, size_t n,
+                                                                 float *s, float *c)
+{
+    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const float v = x[i];
+    float fs, fc;
+    if (which == 0) {
+        dcs_sincos_fast(v, &fs, &fc);
+    } else if (which == 1) {
+        sincosf(v, &fs, &fc); // __ocml_sincos_f32
+    } else {
+        double ds, dc;
+        sincos((double)v, &ds, &dc);
+        fs = (float)ds;
+        fc = (float)dc;
+    }
+    s[i] = fs;
+    c[i] = fc;
+}
+
+template <bool NT>
+__global__ void __launch_bounds__(kBlock) bf_probe_fill_kernel(uintx4 *out, size_t n16)
+{
+    const uintx4 v = {0x3f800000u, 0u, 0x3f800000u, 0u};
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n16; i += (size_t)gridDim.x * kBlock)
+        store_global<NT>(out + i, v);
+}
+
+template <bool OUT16, int TPB, bool NT, bool ALIGNED>
+hipError_t launch_tiled_nm(const bf_tiled_args &a, bool nomath, dim3 grid, hipStream_t stream)
+{
+    if (nomath)
+        hipLaunchKernelGGL((bf_tiled_kernel<OUT16, TPB, NT, ALIGNED, true>), grid, dim3(kBlock), 0, stream, a);
+    else
+        hipLaunchKernelGGL((bf_tiled_kernel<OUT16, TPB, NT, ALIGNED, false>), grid, dim3(kBlock), 0, stream, a);
+    return hipGetLastError();
+}
+
+template <bool OUT16, int TPB>
+hipError_t launch_tiled_t(const bf_tiled_args &a, bool nt, bool aligned, bool nomath, dim3 grid,
+                          hipStream_t stream)
+{
+    if (nt)
+        return aligned ? launch_tiled_nm<OUT16, TPB, true, true>(a, nomath, grid, stream)
+                       : launch_tiled_nm<OUT16, TPB, true, false>(a, nomath, grid, stream);
+    return aligned ? launch_tiled_nm<OUT16, TPB, false, true>(a, nomath, grid, stream)
+                   : launch_tiled_nm<OUT16, TPB, false, false>(a, nomath, grid, stream);
+}
+
+template <bool OUT16>
+hipError_t launch_tiled_o(const bf_tiled_args &a, int tpb, bool nt, bool aligned, bool nomath, dim3 grid,
+                          hipStream_t stream)
+{
+    switch (tpb) {
+    case 1: return launch_tiled_t<OUT16, 1>(a, nt, aligned, nomath, grid, stream);
+    case 2: return launch_tiled_t<OUT16, 2>(a, nt, aligned, nomath, grid, stream);
+    case 4: return launch_tiled_t<OUT16, 4>(a, nt, aligned, nomath, grid, stream);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+} // namespace
+
+hipError_t bf_launch_tiled(const bf_tiled_args &a_in, bool out16, int tiles_per_block, bool nontemporal,
+                           hipStream_t stream)
+{
+    bf_tiled_args a = a_in;
+    if (a.n_pairs == 0 || a.nc == 0 || a.nt == 0) return hipSuccess;
+    if (a.chan_per_block == 0) return hipErrorInvalidValue;
+    const bool nomath = (tiles_per_block & 0x100) != 0; // probe flag, see bf_capi.cpp
+    tiles_per_block &= 0xff;
+    const uint32_t ppl = out16 ? 4u : 2u;
+    const uint32_t pairs_per_block = 64u * ppl * (uint32_t)tiles_per_block;
+    a.n_tile_groups = (a.n_pairs + pairs_per_block - 1) / pairs_per_block;
+    a.n_cblocks = (a.nc + a.chan_per_block - 1) / a.chan_per_block;
+    const uint64_t blocks = (uint64_t)a.n_tile_groups * a.n_cblocks * a.nt;
+    if (blocks == 0 || blocks > 0x7fffffffull) return hipErrorInvalidValue;
+    if (a.dt_dev == nullptr && a.nt != 1) return hipErrorInvalidValue;
+    const bool aligned = (a.n_pairs % ppl) == 0 && (reinterpret_cast<uintptr_t>(a.out) % 16u) == 0;
+    const dim3 grid((uint32_t)blocks);
+    return out16 ? launch_tiled_o<true>(a, tiles_per_block, nontemporal, aligned, nomath, grid, stream)
+                 : launch_tiled_o<false>(a, tiles_per_block, nontemporal, aligned, nomath, grid, stream);
+}
+
+hipError_t bf_launch_naive(const bf_naive_args &a, hipStream_t stream)
+{
+    if (a.n_pairs == 0 || a.nc == 0) return hipSuccess;
+    const dim3 grid((a.n_pairs + kBlock - 1) / kBlock, a.nc < 65535u ? a.nc : 65535u);
+    hipLaunchKernelGGL(bf_naive_kernel, grid, dim3(kBlock), 0, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t bf_launch_gather_beams(dcs_delay_vals *local, const dcs_delay_vals *global, uint32_t n_ant,
+                                  uint32_t n_beams_local, uint32_t n_beams_total, uint32_t beam_offset,
+                                  hipStream_t stream)
+{
+    const uint64_t n = (uint64_t)n_ant * n_beams_local;
+    if (n == 0) return hipSuccess;
+    const dim3 grid((uint32_t)((n + kBlock - 1) / kBlock));
+    hipLaunchKernelGGL(bf_gather_beams_kernel, grid, dim3(kBlock), 0, stream, local, global, n_ant,
+                       n_beams_local, n_beams_total, beam_offset);
+    return hipGetLastError();
+}
+
+hipError_t bf_launch_probe_sincos(int which, const float *x, size_t n, float *s, float *c, hipStream_t stream)
+{
+    if (n == 0) return hipSuccess;
+    const dim3 grid((uint32_t)((n + kBlock - 1) / kBlock));
+    hipLaunchKernelGGL(bf_probe_sincos_kernel, grid, dim3(kBlock), 0, stream, which, x, n, s, c);
+    return hipGetLastError();
+}
+
+hipError_t bf_launch_probe_fill(void *out, size_t bytes, bool nontemporal, hipStream_t stream)
+{
+    const size_t n16 = bytes / 16;
+    if (n16 == 0) return hipSuccess;
+    const dim3 grid(256 * 8);
+    if (nontemporal)
+        hipLaunchKernelGGL(bf_probe_fill_kernel<true>, grid, dim3(kBlock), 0, stream,
+                           reinterpret_cast<uintx4 *>(out), n16);
+    else
+        hipLaunchKernelGGL(bf_probe_fill_kernel<false>, grid, dim3(kBlock), 0, stream,
+                           reinterpret_cast<uintx4 *>(out), n16);
+    return hipGetLastError();
+}

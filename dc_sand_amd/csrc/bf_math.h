@@ -1,0 +1,199 @@
+// bf_math.h -- the fp32 arithmetic of the steering-coefficient hot path.
+//
+// One definition, two compilers: hipcc (device code, gfx950) for the kernels in
+// bf_kernels.hip, and gcc for tests/numerics (a host build used ONLY to sweep
+// these exact operation sequences exhaustively against the oracle; it is not a
+// product fallback and nothing in dc_sand_amd/ loads it).
+//
+// Every operation here is a single IEEE fp32/fp64 operation with one rounding:
+// fused multiply-adds are written as dcs_fmaf(), everything else must stay
+// unfused -- both builds use -ffp-contract=off.  The sequence to reproduce is
+// the reference CPU verifier's (beamformer_coefficient_generator/
+// BeamformerCoefficientTest.cu:321-328).
+#ifndef DCS_BF_MATH_H
+#define DCS_BF_MATH_H
+
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define DCS_HD __host__ __device__ __forceinline__
+#else
+#define DCS_HD static inline __attribute__((always_inline))
+#endif
+
+#define dcs_fmaf(a, b, c) __builtin_fmaf((a), (b), (c))
+
+// (float)M_PI, the constant the reference multiplies by (.cu:322-323).
+#define DCS_PI_F 3.14159274101257324219f
+
+// 16-byte table entry: beamformer_coefficient_generator/BeamformerParameters.h:61-66
+// (also declared, identically, by include/dcs_beamformer.h)
+#ifndef DCS_DELAY_VALS_DEFINED
+#define DCS_DELAY_VALS_DEFINED
+struct dcs_delay_vals {
+    float fDelay_s;
+    float fDelayRate_sps;
+    float fPhase_rad;
+    float fPhaseRate_radps;
+};
+#endif
+
+// Per-launch constants derived on the host from (SAMPLING_PERIOD, NR_CHANNELS).
+struct dcs_bf_consts {
+    float fDenominator;      // SAMPLING_PERIOD * NR_CHANNELS, fp32 product (.cu:322)
+    float fRcpDenominator;   // RN(1 / fDenominator), fp32 divide on the host
+    float fRotBoundScale;    // >= pi * (NR_CHANNELS-1) / fDenominator, with margin
+    float fPad;
+    double dHalfChannels;    // NR_CHANNELS / 2.0 (.cu:323)
+    double dDenominator;     // (double) fDenominator (.cu:323)
+};
+
+// ---------------------------------------------------------------------------
+// Per-(antenna, beam, time) terms that do not depend on the channel:
+//   fRateTerm = fDelayRate_sps + fDeltaDelay                (.cu:321-322)
+//   fPhase0   = fPhase_rad - fDelayN2 + fDeltaPhase         (.cu:323-325)
+// fDelayN2 is the one double-precision chain of the verifier: the fp32 sum
+// (fDelay_s + fDeltaDelay) is promoted, multiplied by NR_CHANNELS/2.0 and
+// (double)(float)M_PI, divided by (double)(SAMPLING_PERIOD*NR_CHANNELS) and
+// rounded to fp32 once.
+// ---------------------------------------------------------------------------
+DCS_HD void dcs_pair_terms(const dcs_delay_vals d, const float fDeltaTime,
+                           const double dHalfChannels, const double dDenominator,
+                           float *fRateTerm, float *fPhase0)
+{
+    const float fDeltaDelay = d.fDelayRate_sps * fDeltaTime;
+    const float fRate = d.fDelayRate_sps + fDeltaDelay;
+    const float fSum = d.fDelay_s + fDeltaDelay;
+    const double dN2 = (((double)fSum * dHalfChannels) * (double)DCS_PI_F) / dDenominator;
+    const float fDelayN2 = (float)dN2;
+    const float fDeltaPhase = d.fPhaseRate_radps * fDeltaTime;
+    const float fDiff = d.fPhase_rad - fDelayN2;
+    *fRateTerm = fRate;
+    *fPhase0 = fDiff + fDeltaPhase;
+}
+
+// ---------------------------------------------------------------------------
+// Correctly rounded x / D for a launch-constant D, without the hardware divide
+// sequence: y = RN(1/D); two Markstein correction steps.  q1 is within half an
+// ulp (+2^-47 relative) of x/D, hence faithful; with r1 = x - q1*D exact (fma),
+// RN(q1 + r1*y) is the correctly rounded quotient (Markstein 1990, Thm. 8.5 in
+// Muller et al., "Handbook of Floating-Point Arithmetic").  Valid while no
+// intermediate under/overflows: callers guarantee 2^-60 <= |x| <= 2^90 or
+// x == 0 and 2^-40 <= D <= 2^40 (dcs_rate_in_fast_range + host check).
+// tests/numerics sweeps it against the IEEE divide.
+// ---------------------------------------------------------------------------
+DCS_HD float dcs_div_const(const float x, const float D, const float y)
+{
+    const float q0 = x * y;
+    const float r0 = dcs_fmaf(-q0, D, x);
+    const float q1 = dcs_fmaf(r0, y, q0);
+    const float r1 = dcs_fmaf(-q1, D, x);
+    return dcs_fmaf(r1, y, q1);
+}
+
+// fRotation for channel c (.cu:322,326): three fp32 roundings for fDelayN
+// (mul, mul, divide) and one add.
+DCS_HD float dcs_rotation(const float fRateTerm, const float fPhase0, const float fChannel,
+                          const float D, const float y)
+{
+    const float m1 = fRateTerm * fChannel;
+    const float m2 = m1 * DCS_PI_F;
+    const float fDelayN = dcs_div_const(m2, D, y);
+    return fDelayN + fPhase0;
+}
+
+// Same with the IEEE divide (slow path: operands outside dcs_div_const's range).
+DCS_HD float dcs_rotation_ieee(const float fRateTerm, const float fPhase0, const float fChannel,
+                               const float D)
+{
+    const float m1 = fRateTerm * fChannel;
+    const float m2 = m1 * DCS_PI_F;
+    const float fDelayN = m2 / D;
+    return fDelayN + fPhase0;
+}
+
+DCS_HD uint32_t dcs_f32_bits(const float f) { return __builtin_bit_cast(uint32_t, f); }
+DCS_HD float dcs_bits_f32(const uint32_t u) { return __builtin_bit_cast(float, u); }
+
+// |fRateTerm| in [2^-60, 2^60] or zero: dcs_div_const is exact for every channel
+// index up to 2^24.
+DCS_HD bool dcs_rate_in_fast_range(const float fRateTerm)
+{
+    const uint32_t e = (dcs_f32_bits(fRateTerm) >> 23) & 0xffu;
+    return (fRateTerm == 0.0f) || (e >= 127u - 60u && e <= 127u + 60u);
+}
+
+// A pair may take the fast path (dcs_div_const + dcs_sincos_fast) for every
+// channel of the launch iff its rate term is in dcs_div_const's range and
+// |fRotation| is provably below DCS_SINCOS_FAST_LIMIT: |fDelayN| <=
+// |fRateTerm| * pi*(C-1)/D * (1 + 2^-21).  NaN/Inf fail every comparison and
+// take the slow path.
+DCS_HD bool dcs_pair_is_fast(const float fRateTerm, const float fPhase0, const float fRotBoundScale)
+{
+    const float bound = __builtin_fabsf(fRateTerm) * fRotBoundScale + __builtin_fabsf(fPhase0);
+    return dcs_rate_in_fast_range(fRateTerm) && (bound < 32000.0f);
+}
+
+// ---------------------------------------------------------------------------
+// sin and cos of an fp32 argument, |x| < DCS_SINCOS_FAST_LIMIT, each within
+// 1 ULP of the correctly rounded value ((float)sin((double)x), .cu:327-328).
+// tests/test_numerics.py checks EVERY fp32 in the range (proof by exhaustion;
+// nothing here is a statistical claim).
+//
+// Reduction: the quotient n = rint(x * 2/pi) comes out of the low mantissa bits
+// of x*(2/pi) + 1.5*2^23 (no float->int convert); r = x - n*pi/2 with pi/2
+// split in three fp32 parts (Cody-Waite with fma).  The first step is exact (x
+// and n*P1 agree to ~pi/4 and both sit on a 2^-24 grid), the second and third
+// round once each, so r carries one half-ulp of error.
+// Polynomials on [-pi/4, pi/4]: sin r = r + r*s*Ps(s), cos r = 1 + s*Pc(s),
+// s = r*r; the last operation of each adds a small correction to r or to 1.
+// Quadrant q = n mod 4 rotates (cos r, sin r) by q quarter turns.
+// ---------------------------------------------------------------------------
+#define DCS_SINCOS_FAST_LIMIT 32768.0f
+
+#define DCS_TWO_OVER_PI 0.636619746685028076171875f   // RN(2/pi)
+#define DCS_RINT_MAGIC 12582912.0f                      // 1.5 * 2^23
+#define DCS_PIO2_1 1.57079637050628662109375f          // RN(pi/2)
+#define DCS_PIO2_2 -4.37113882867379114032e-08f        // RN(pi/2 - P1)
+#define DCS_PIO2_3 -1.71512451733121152534e-15f        // RN(pi/2 - P1 - P2)
+
+// sin(r) ~ r + r*s*(S1 + s*(S2 + s*(S3 + s*S4))),  s = r*r
+#define DCS_S1 -1.66666671633720397949e-01f
+#define DCS_S2 8.33333376795053482056e-03f
+#define DCS_S3 -1.98412701138295233250e-04f
+#define DCS_S4 2.75573142971552442759e-06f
+// cos(r) ~ 1 + s*(-1/2 + s*(C1 + s*(C2 + s*(C3 + s*C4))))
+#define DCS_C1 4.16666679084300994873e-02f
+#define DCS_C2 -1.38888892251998186111e-03f
+#define DCS_C3 2.48015876422869041562e-05f
+#define DCS_C4 -2.75573142971552442759e-07f
+
+DCS_HD void dcs_sincos_fast(const float x, float *fSin, float *fCos)
+{
+    const float nb = dcs_fmaf(x, DCS_TWO_OVER_PI, DCS_RINT_MAGIC);
+    const float n = nb - DCS_RINT_MAGIC;
+    const uint32_t q = dcs_f32_bits(nb);                   // low bits = n mod 2^22
+    float r = dcs_fmaf(-n, DCS_PIO2_1, x);                 // exact
+    r = dcs_fmaf(-n, DCS_PIO2_2, r);
+    r = dcs_fmaf(-n, DCS_PIO2_3, r);
+    const float s = r * r;
+
+    float ps = dcs_fmaf(s, DCS_S4, DCS_S3);
+    ps = dcs_fmaf(ps, s, DCS_S2);
+    ps = dcs_fmaf(ps, s, DCS_S1);
+    float pc = dcs_fmaf(s, DCS_C4, DCS_C3);
+    pc = dcs_fmaf(pc, s, DCS_C2);
+    pc = dcs_fmaf(pc, s, DCS_C1);
+    pc = dcs_fmaf(pc, s, -0.5f);
+    const float sr = dcs_fmaf(s * r, ps, r);
+    const float cr = dcs_fmaf(s, pc, 1.0f);
+
+    // q mod 4:  0: (cr, sr)  1: (-sr, cr)  2: (-cr, -sr)  3: (sr, -cr)
+    const bool swap = (q & 1u) != 0u;
+    const uint32_t sin_sign = (q << 30) & 0x80000000u;      // bit 1 of q
+    const uint32_t cos_sign = sin_sign ^ (q << 31);         // bit 1 xor bit 0
+    *fSin = dcs_bits_f32(dcs_f32_bits(swap ? cr : sr) ^ sin_sign);
+    *fCos = dcs_bits_f32(dcs_f32_bits(swap ? sr : cr) ^ cos_sign);
+}
+
+#endif // DCS_BF_MATH_H

@@ -1,0 +1,159 @@
+"""Object wrapper over the hot-path entry points of the C-ABI.
+
+``SteeringCoefficientGenerator`` owns one ``dcs_bf_context`` (device delay
+table, double-buffered) for a fixed shape; output buffers belong to the caller
+(a :class:`dc_sand_amd.device.DeviceAllocation`, a raw device pointer, or a
+torch CUDA tensor's ``data_ptr()``).
+"""
+from __future__ import annotations
+
+import ctypes
+from ctypes import byref, c_float, c_size_t, c_void_p
+
+import numpy as np
+
+from . import _lib
+from ._lib import B16, B32, MULTIPLE_CHANNELS_AND_TIMESTAMPS, check
+from .device import _s
+from .parameters import BeamformerParameters, delay_vals_dtype
+
+
+def delta_times(params: BeamformerParameters, t0: int, nt: int) -> np.ndarray:
+    """fDeltaTime of the reference verifier for time indices [t0, t0+nt)
+    (``BeamformerCoefficientTest.cu:299`` then ``:12-18``).  Host only."""
+    out = np.empty(nt, dtype=np.float32)
+    cp = params.to_c()
+    check(
+        _lib.lib().dcs_bf_delta_times(byref(cp), int(t0), int(nt), out.ctypes.data_as(ctypes.POINTER(c_float))),
+        "dcs_bf_delta_times",
+    )
+    return out
+
+
+def simulate_input(params: BeamformerParameters) -> np.ndarray:
+    """The reference's linear-ramp table (``BeamformerCoefficientTest.cu:185-196``)."""
+    out = np.empty(params.n_pairs, dtype=delay_vals_dtype)
+    cp = params.to_c()
+    check(_lib.lib().dcs_bf_simulate_input(byref(cp), c_void_p(out.ctypes.data)), "dcs_bf_simulate_input")
+    return out
+
+
+def output_bytes(params: BeamformerParameters, bitwidth: int, nt: int) -> int:
+    n = c_size_t(0)
+    cp = params.to_c()
+    check(_lib.lib().dcs_bf_output_bytes(byref(cp), int(bitwidth), int(nt), byref(n)), "dcs_bf_output_bytes")
+    return int(n.value)
+
+
+def gpu_utilisation(params: BeamformerParameters, kernel_ms: float) -> tuple[float, float]:
+    """``BeamformerCoeffTest::get_time`` model (``BeamformerCoefficientTest.cu:426-448``)."""
+    out = (c_float * 2)()
+    cp = params.to_c()
+    check(_lib.lib().dcs_bf_gpu_utilisation(byref(cp), float(kernel_ms), out), "dcs_bf_gpu_utilisation")
+    return float(out[0]), float(out[1])
+
+
+class SteeringCoefficientGenerator:
+    def __init__(self, params: BeamformerParameters):
+        self.params = params
+        self._cp = params.to_c()
+        h = c_void_p()
+        check(_lib.lib().dcs_bf_create(byref(self._cp), byref(h)), "dcs_bf_create")
+        self._h = h.value
+        self._host_table = None  # keeps the last uploaded table alive during the async copy
+
+    # -- delay table ------------------------------------------------------
+    def upload_delays(self, table: np.ndarray, stream=None) -> None:
+        """transfer_HtoD (``BeamformerCoefficientTest.cu:207-216``)."""
+        table = np.ascontiguousarray(table)
+        if table.dtype != delay_vals_dtype or table.size != self.params.n_pairs:
+            raise ValueError(f"delay table must be {self.params.n_pairs} x delay_vals_dtype")
+        self._host_table = table
+        check(_lib.lib().dcs_bf_upload_delays(c_void_p(self._h), c_void_p(table.ctypes.data), _s(stream)), "dcs_bf_upload_delays")
+
+    def set_delays_from_global(self, d_global_table: int, nr_beams_total: int, beam_offset: int, stream=None) -> None:
+        """Take beams [beam_offset, beam_offset+NR_BEAMS) of a device-resident
+        global table [NR_STATIONS][nr_beams_total] (multi-GPU beam sharding)."""
+        check(
+            _lib.lib().dcs_bf_set_delays_from_global(
+                c_void_p(self._h), c_void_p(int(d_global_table)), int(nr_beams_total), int(beam_offset), _s(stream)
+            ),
+            "dcs_bf_set_delays_from_global",
+        )
+
+    # -- generation -------------------------------------------------------
+    def generate(self, d_out, out_bytes: int, t0: int = 0, nt: int = 1, kernel: int = MULTIPLE_CHANNELS_AND_TIMESTAMPS,
+                 bitwidth: int = B32, stream=None) -> None:
+        """run_kernel (``BeamformerCoefficientTest.cu:218-264``)."""
+        check(
+            _lib.lib().dcs_bf_generate(c_void_p(self._h), int(kernel), int(bitwidth), int(t0), int(nt), c_void_p(int(d_out)),
+                                       int(out_bytes), _s(stream)),
+            "dcs_bf_generate",
+        )
+
+    def generate_slab(self, d_out, out_bytes: int, c0: int, nc: int, t0: int = 0, nt: int = 1, bitwidth: int = B32,
+                      stream=None) -> None:
+        check(
+            _lib.lib().dcs_bf_generate_slab(c_void_p(self._h), int(bitwidth), int(t0), int(nt), int(c0), int(nc),
+                                            c_void_p(int(d_out)), int(out_bytes), _s(stream)),
+            "dcs_bf_generate_slab",
+        )
+
+    def set_tuning(self, chan_per_block: int = 0, tiles_per_block: int = 0, nontemporal: int = -1, nomath: bool = False) -> None:
+        check(
+            _lib.lib().dcs_bf_set_tuning(c_void_p(self._h), int(chan_per_block), int(tiles_per_block) | (0x100 if nomath else 0),
+                                         int(nontemporal)),
+            "dcs_bf_set_tuning",
+        )
+
+    def output_bytes(self, bitwidth: int = B32, nt: int = 1) -> int:
+        return output_bytes(self.params, bitwidth, nt)
+
+    # -- streaming (config 5) ---------------------------------------------
+    def stream_begin(self, d_out, out_bytes: int, c0: int, nc: int, stream, bitwidth: int = B32) -> "CoefficientStream":
+        h = c_void_p()
+        check(
+            _lib.lib().dcs_bf_stream_begin(c_void_p(self._h), int(bitwidth), int(c0), int(nc), c_void_p(int(d_out)), int(out_bytes),
+                                           _s(stream), byref(h)),
+            "dcs_bf_stream_begin",
+        )
+        return CoefficientStream(self, h.value)
+
+    def close(self) -> None:
+        if self._h:
+            _lib.lib().dcs_bf_destroy(c_void_p(self._h))
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class CoefficientStream:
+    """hipGraph replay of one time step per tick (BASELINE config 5)."""
+
+    def __init__(self, gen: SteeringCoefficientGenerator, handle: int):
+        self._gen = gen
+        self._h = handle
+
+    def tick(self, t: int, new_table: np.ndarray | None = None) -> None:
+        ptr = c_void_p(None)
+        if new_table is not None:
+            new_table = np.ascontiguousarray(new_table)
+            if new_table.dtype != delay_vals_dtype or new_table.size != self._gen.params.n_pairs:
+                raise ValueError("bad delay table")
+            ptr = c_void_p(new_table.ctypes.data)
+        check(_lib.lib().dcs_bf_stream_tick(c_void_p(self._h), int(t), ptr), "dcs_bf_stream_tick")
+
+    def end(self) -> None:
+        if self._h:
+            _lib.lib().dcs_bf_stream_end(c_void_p(self._h))
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.end()
+        except Exception:
+            pass

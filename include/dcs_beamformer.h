@@ -1,0 +1,195 @@
+/*
+ * dcs_beamformer.h -- C-ABI of the MI355X (gfx950) steering-coefficient
+ * generator: the drop-in boundary for the one hot path of ska-sa/dc_sand's
+ * beamformer_coefficient_generator/.
+ *
+ * Every entry point is `extern "C"`, takes plain pointers / sizes / scalars,
+ * returns an int status (0 = DCS_OK, > 0 = a hipError_t value, < 0 = one of the
+ * DCS_ERR_* codes below) and never exits, throws or prints.  All device work is
+ * enqueued on the caller's hipStream_t (passed as void*, NULL = the null
+ * stream) so the calls can be captured in a hipGraph; nothing here starts host
+ * threads.
+ *
+ * Each declaration cites the reference interface it replaces (paths relative
+ * to the reference root; "BCT" = beamformer_coefficient_generator/
+ * BeamformerCoefficientTest).  INTEGRATION.md shows the reference-side stub.
+ *
+ * Library: dc_sand_amd/csrc/libdcs_beamformer.so (built by `python -m
+ * dc_sand_amd.build` or __graft_entry__.build()).
+ */
+#ifndef DCS_BEAMFORMER_H
+#define DCS_BEAMFORMER_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DCS_BF_ABI_VERSION 1
+
+/* ---- status codes ------------------------------------------------------- */
+#define DCS_OK 0
+#define DCS_ERR_INVALID_ARGUMENT (-1)
+#define DCS_ERR_UNSUPPORTED (-2)   /* the reference `throw`s here: BCT.cu:40-50 */
+#define DCS_ERR_NOT_READY (-3)     /* e.g. generate before a delay table is set */
+#define DCS_ERR_OUT_OF_RANGE (-4)
+#define DCS_ERR_NO_DEVICE (-5)
+
+/* "<HIP Error|dcs error>: <text>", cf. common/Utils.cpp:8-16 (gpu_assert prints
+ * and exit()s; here the caller decides). Returns a static string. */
+const char *dcs_error_string(int status);
+int dcs_abi_version(void);
+
+/* ---- data contract ------------------------------------------------------ */
+
+/* BeamformerParameters.h:61-66 -- 4 x fp32, 16 bytes, no padding; the table is
+ * indexed [antenna * nr_beams + beam] (BCT.cu:315; BeamformerKernels.cu:22,79). */
+#ifndef DCS_DELAY_VALS_DEFINED
+#define DCS_DELAY_VALS_DEFINED
+struct dcs_delay_vals {
+    float fDelay_s;
+    float fDelayRate_sps;
+    float fPhase_rad;
+    float fPhaseRate_radps;
+};
+#endif
+
+/* BCT.hpp:19-25 (enum SteeringCoefficientKernel) -- same order, same values. */
+enum dcs_bf_kernel {
+    DCS_BF_NAIVE = 0,
+    DCS_BF_MULTIPLE_CHANNELS = 1,
+    DCS_BF_MULTIPLE_CHANNELS_AND_TIMESTAMPS = 2,
+    DCS_BF_COMBINED_COEFF_GEN_AND_BEAMFORMER_SINGLE_CHANNEL = 3 /* DCS_ERR_UNSUPPORTED */
+};
+
+/* BCT.hpp:33-37 (enum SteeringCoefficientBitWidth). */
+enum dcs_bf_bitwidth { DCS_BF_B16 = 0, DCS_BF_B32 = 1 };
+
+/* Run-time stand-ins for the compile-time macros of BeamformerParameters.h:4-17.
+ * dcs_bf_default_params() fills the header's values (64 chan, 64 ant, 16 beams,
+ * 256 samples, 1e-7f, 8192, 1712e6, 256). */
+struct dcs_bf_params {
+    int32_t nr_channels;                     /* NR_CHANNELS */
+    int32_t nr_stations;                     /* NR_STATIONS */
+    int32_t nr_beams;                        /* NR_BEAMS (beams held by THIS context) */
+    int32_t nr_samples_per_channel;          /* NR_SAMPLES_PER_CHANNEL */
+    float sampling_period;                   /* SAMPLING_PERIOD */
+    int32_t fft_size;                        /* FFT_SIZE */
+    double adc_sample_rate;                  /* ADC_SAMPLE_RATE */
+    int32_t accumulations_before_new_coeffs; /* ACCUMULATIONS_BEFORE_NEW_COEFFS */
+    int32_t reserved;
+};
+int dcs_bf_default_params(struct dcs_bf_params *p);
+
+/* Output layout (BCT.cu:331-333; BeamformerKernels.cu:47-49,175-177,181-184):
+ *   b32: float  [nt][nr_channels][nr_stations][nr_beams][2]   (re, im)
+ *   b16: __half2[nt][nr_channels][nr_stations][nr_beams]      (.x = re, .y = im)
+ * Size as BCT.cu:32-38. */
+int dcs_bf_output_bytes(const struct dcs_bf_params *p, int bitwidth, uint32_t nt, size_t *bytes);
+
+/* fDeltaTime of the verifier for time indices [t0, t0+nt): BCT.cu:299 (fp32
+ * time step in ns, truncated) then ts_diff, BCT.cu:12-18.  Host only.  This is
+ * the dt every kernel variant uses. */
+int dcs_bf_delta_times(const struct dcs_bf_params *p, uint64_t t0, uint32_t nt, float *dt_out);
+
+/* simulate_input(), BCT.cu:185-196: the reference's linear-ramp table for
+ * n = nr_stations*nr_beams entries.  Host only. */
+int dcs_bf_simulate_input(const struct dcs_bf_params *p, struct dcs_delay_vals *table_out);
+
+/* ---- device plumbing (the pycuda calls of pycuda_example/vector_add.py:14-46) */
+int dcs_device_count(int *count);
+int dcs_device_set(int device);
+int dcs_device_synchronize(void);
+int dcs_device_name(int device, char *buf, size_t buflen);
+int dcs_malloc(void **dptr, size_t bytes);                 /* cuda.mem_alloc / cudaMalloc BCT.cu:74,78 */
+int dcs_free(void *dptr);                                  /* cudaFree BCT.cu:95,99 */
+int dcs_host_alloc(void **hptr, size_t bytes);             /* cuda.pagelocked_empty / cudaMallocHost BCT.cu:73,77 */
+int dcs_host_free(void *hptr);                             /* cudaFreeHost BCT.cu:96,100 */
+int dcs_memcpy_htod(void *dptr, const void *hptr, size_t bytes, void *stream); /* BCT.cu:210 */
+int dcs_memcpy_dtoh(void *hptr, const void *dptr, size_t bytes, void *stream); /* BCT.cu:270 */
+int dcs_memcpy_dtod(void *dst, const void *src, size_t bytes, void *stream);
+/* Strided device->host gather of rows: nrows rows of row_bytes, src pitch src_pitch. */
+int dcs_memcpy2d_dtoh(void *hptr, size_t dst_pitch, const void *dptr, size_t src_pitch,
+                      size_t row_bytes, size_t nrows, void *stream);
+int dcs_memset(void *dptr, int value, size_t bytes, void *stream);
+int dcs_stream_create(void **stream);
+int dcs_stream_destroy(void *stream);
+int dcs_stream_synchronize(void *stream);
+
+/* Event timing of UnitTest::run_test (common/UnitTest.cpp:9-14,34-53). */
+int dcs_event_create(void **event);
+int dcs_event_destroy(void *event);
+int dcs_event_record(void *event, void *stream);
+int dcs_event_synchronize(void *event);
+int dcs_event_elapsed_ms(void *start, void *stop, float *ms);
+
+/* ---- the hot path ------------------------------------------------------- */
+typedef struct dcs_bf_context dcs_bf_context;
+
+/* Owns the device delay table (double-buffered) and the per-launch dt slots for
+ * the given shape on the current device; replaces the buffer ownership of
+ * BeamformerCoeffTest's ctor/dtor (BCT.cu:73-87,93-109).  Output buffers belong
+ * to the caller.  Shape guards return DCS_ERR_INVALID_ARGUMENT. */
+int dcs_bf_create(const struct dcs_bf_params *p, dcs_bf_context **ctx);
+int dcs_bf_destroy(dcs_bf_context *ctx);
+
+/* transfer_HtoD(), BCT.cu:207-216: copy a host table of nr_stations*nr_beams
+ * entries into the context (async on `stream`; `table` must stay valid until
+ * the stream reaches the copy -- use pinned memory for true overlap). */
+int dcs_bf_upload_delays(dcs_bf_context *ctx, const struct dcs_delay_vals *table, void *stream);
+
+/* Multi-GPU entry: take this context's beam slice out of a device-resident
+ * GLOBAL table [nr_stations][nr_beams_total] (e.g. just broadcast by RCCL):
+ * local beam b is global beam beam_offset + b.  Device-side gather on `stream`. */
+int dcs_bf_set_delays_from_global(dcs_bf_context *ctx, const void *d_global_table,
+                                  uint32_t nr_beams_total, uint32_t beam_offset, void *stream);
+
+/* run_kernel(), BCT.cu:218-264.  Writes time indices [t0, t0+nt) into d_out
+ * (layout above, time index t0 first).  `kernel` keeps the reference's launch
+ * shapes: NAIVE and MULTIPLE_CHANNELS issue one launch per time step from a
+ * host loop (BCT.cu:230-250), MULTIPLE_CHANNELS_AND_TIMESTAMPS one launch for
+ * all of them (BCT.cu:253-257).  NAIVE + B16 and COMBINED return
+ * DCS_ERR_UNSUPPORTED (BCT.cu:40-50).  All variants compute the verifier's
+ * arithmetic (BCT.cu:319-328) and agree bit for bit with each other. */
+int dcs_bf_generate(dcs_bf_context *ctx, int kernel, int bitwidth, uint64_t t0, uint32_t nt,
+                    void *d_out, size_t out_bytes, void *stream);
+
+/* As dcs_bf_generate(MULTIPLE_CHANNELS_AND_TIMESTAMPS) for the channel slab
+ * [c0, c0+nc) only; d_out is the slab tensor [nt][nc][stations][beams]. */
+int dcs_bf_generate_slab(dcs_bf_context *ctx, int bitwidth, uint64_t t0, uint32_t nt,
+                         uint32_t c0, uint32_t nc, void *d_out, size_t out_bytes, void *stream);
+
+/* Tuning knobs (0 = library default): channels per workgroup, 128-pair tiles
+ * per workgroup (1, 2 or 4), nontemporal stores (0/1; -1 = default). */
+int dcs_bf_set_tuning(dcs_bf_context *ctx, int chan_per_block, int tiles_per_block, int nontemporal);
+
+/* get_time(), BCT.cu:422-454: the real-time utilisation model, from a kernel
+ * duration in ms.  out[0] = per single time unit, out[1] = per
+ * ACCUMULATIONS_BEFORE_NEW_COEFFS time units (both x4 as BCT.cu:447-448). */
+int dcs_bf_gpu_utilisation(const struct dcs_bf_params *p, float kernel_ms, float out[2]);
+
+/* ---- streaming (BASELINE config 5) -------------------------------------- */
+/* Captures {dt upload -> generate one time step} into a hipGraph per delay-table
+ * buffer.  Each tick replays it for time index t; a non-NULL new_table is
+ * uploaded into the idle table buffer first and becomes current.  The slab
+ * [c0, c0+nc) x all (antenna, beam) of one time step is rewritten in place. */
+typedef struct dcs_bf_stream dcs_bf_stream;
+int dcs_bf_stream_begin(dcs_bf_context *ctx, int bitwidth, uint32_t c0, uint32_t nc, void *d_out,
+                        size_t out_bytes, void *stream, dcs_bf_stream **s);
+int dcs_bf_stream_tick(dcs_bf_stream *s, uint64_t t, const struct dcs_delay_vals *new_table);
+int dcs_bf_stream_end(dcs_bf_stream *s);
+
+/* ---- probes (used by tests / bench to characterise the device) ----------- */
+/* Device evaluation of the two sincos forms on n arguments:
+ * which = 0 the library's fast path, 1 __ocml_sincos_f32, 2 the fp64 slow path. */
+int dcs_probe_sincos(int which, const float *d_x, size_t n, float *d_sin, float *d_cos, void *stream);
+/* Pure store kernel with the generator's access pattern and no arithmetic: the
+ * measured HBM-write ceiling the roofline fraction is read against. */
+int dcs_probe_fill(void *d_out, size_t bytes, int nontemporal, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DCS_BEAMFORMER_H */

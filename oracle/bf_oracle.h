@@ -1,0 +1,128 @@
+/*
+ * bf_oracle.h -- CPU restatement of the dc_sand beamformer steering-coefficient
+ * verifier.  TEST INFRASTRUCTURE ONLY.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load this library; the product path (dc_sand_amd/) never does.
+ *
+ * PARITY STATUS: "parity unpinned".  The reference tree
+ * (beamformer_coefficient_generator/) stores no golden vectors and cannot be
+ * compiled in this image (it needs cuComplex.h / cuda_runtime_api.h), so the
+ * restatement is pinned only procedurally: by the reference's own synthetic
+ * input recipe (simulate_input) and by its acceptance rule
+ * |kernel - verifier| <= 1e-4 (runBeamformerTests.cpp:30,61), which
+ * tests/test_oracle.py re-runs between this file's verifier restatement and its
+ * restatement of the reference's device arithmetic.
+ *
+ * Every function cites the reference lines it follows (paths relative to the
+ * reference root).
+ */
+#ifndef DCS_BF_ORACLE_H
+#define DCS_BF_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+#include <time.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* beamformer_coefficient_generator/BeamformerParameters.h:61-66 */
+struct dcs_oracle_delay_vals {
+    float fDelay_s;
+    float fDelayRate_sps;
+    float fPhase_rad;
+    float fPhaseRate_radps;
+};
+
+/* Run-time stand-ins for the compile-time macros of
+ * BeamformerParameters.h:7-17 (NR_CHANNELS, NR_STATIONS, NR_BEAMS,
+ * SAMPLING_PERIOD, FFT_SIZE). */
+struct dcs_oracle_params {
+    int32_t nr_channels;
+    int32_t nr_stations;
+    int32_t nr_beams;
+    float sampling_period; /* SAMPLING_PERIOD 1e-7f */
+    int32_t fft_size;      /* FFT_SIZE 8192 */
+};
+
+/* Defaults of BeamformerParameters.h (64 chan, 64 ant, 16 beams). */
+void dcs_oracle_default_params(struct dcs_oracle_params *p);
+
+/* BeamformerCoefficientTest.cu:12-18 */
+float dcs_oracle_ts_diff(struct timespec first, struct timespec last);
+
+/* BeamformerCoefficientTest.cu:299 -- verifier's time step in ns. */
+long dcs_oracle_time_step_ns(const struct dcs_oracle_params *p, size_t t);
+
+/* BeamformerCoefficientTest.cu:235,247 -- the launch loop's time step in ns
+ * (double 1e9); differs from the verifier's at some t.  Reported only. */
+long dcs_oracle_time_step_ns_launch_loop(const struct dcs_oracle_params *p, size_t t);
+
+/* BeamformerCoefficientTest.cu:296-300,320 -- fDeltaTime for time index t,
+ * with the reference time given explicitly (it cancels). */
+float dcs_oracle_delta_time(const struct dcs_oracle_params *p, size_t t,
+                            struct timespec ref);
+
+/* BeamformerCoefficientTest.cu:185-196 -- linear-ramp synthetic input for
+ * n = nr_stations*nr_beams entries. */
+void dcs_oracle_simulate_input(const struct dcs_oracle_params *p,
+                               struct dcs_oracle_delay_vals *out);
+
+/* BeamformerCoefficientTest.cu:319-328 -- one coefficient. */
+void dcs_oracle_coeff(const struct dcs_oracle_params *p,
+                      struct dcs_oracle_delay_vals d, float fDeltaTime,
+                      size_t c, float *re, float *im);
+/* Same, returning only fRotation (:326). */
+float dcs_oracle_rotation(const struct dcs_oracle_params *p,
+                          struct dcs_oracle_delay_vals d, float fDeltaTime,
+                          size_t c);
+
+/* BeamformerCoefficientTest.cu:294-337 -- expected coefficients for time
+ * indices [t0, t0+nt) and channels [c0, c0+nc), written as
+ * out[((t-t0)*nc + (c-c0))*A*B + a*B + b][2].  With c0=0, nc=nr_channels this
+ * is the reference tensor [t][c][a][b][2] (:331-333).  Returns seconds spent
+ * (steady clock, as :289,338). */
+double dcs_oracle_generate(const struct dcs_oracle_params *p,
+                           const struct dcs_oracle_delay_vals *delays,
+                           size_t t0, size_t nt, size_t c0, size_t nc,
+                           float *out);
+
+/* Same loop, no output tensor: returns an order-independent checksum (sum of
+ * the fp32 bit patterns, mod 2^64) over the same elements and the seconds
+ * spent.  nthreads > 1 splits the channel range over pthreads (the reference
+ * is serial; nthreads == 1 is the faithful baseline). */
+double dcs_oracle_generate_checksum(const struct dcs_oracle_params *p,
+                                    const struct dcs_oracle_delay_vals *delays,
+                                    size_t t0, size_t nt, size_t c0, size_t nc,
+                                    int nthreads, uint64_t *checksum);
+
+/* BeamformerCoefficientTest.cu:348-359 -- first index where
+ * |got - expect| > tol, or -1 (=> m_iResult 1). */
+int64_t dcs_oracle_compare(const float *got, const float *expect, size_t n,
+                           float tol);
+
+/* Added: ULP distance (ordered-integer difference of the bit patterns);
+ * max over n elements, count of elements with distance > limit. */
+uint32_t dcs_oracle_ulp_diff(float a, float b);
+uint32_t dcs_oracle_max_ulp(const float *got, const float *expect, size_t n,
+                            uint32_t limit, uint64_t *n_over, int64_t *first_over);
+
+/* Restatement of the reference's DEVICE arithmetic, kernel a3
+ * (BeamformerKernels.cu:153-177): dt = t*Ts*FFT in fp32, integer
+ * NR_CHANNELS/2, all-fp32 fDelayN2, and a sincosf stand-in
+ * ((float)cos/sin of the double).  Used only to re-run the reference's own
+ * acceptance rule against the verifier restatement. */
+void dcs_oracle_device_variant_a3(const struct dcs_oracle_params *p,
+                                  const struct dcs_oracle_delay_vals *delays,
+                                  size_t t0, size_t nt, float *out);
+
+/* fp16 (f2): IEEE binary16 round-to-nearest-even of an fp32, as
+ * __floats2half2_rn does per element (BeamformerKernels.cu:113,182). */
+uint16_t dcs_oracle_f32_to_f16_rn(float x);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,163 @@
+/*
+ * numerics_lab.c -- host build of dc_sand_amd/csrc/bf_math.h, used ONLY by the
+ * tests to sweep the device operation sequences exhaustively on the CPU (an
+ * fp32 fma / mul / add / rint gives the same bits on x86-64 and on gfx950).
+ * Test infrastructure: never loaded by dc_sand_amd/.
+ *
+ * Build: g++ -O2 -ffp-contract=off [-mfma] -shared -fPIC (tests/numerics/Makefile)
+ */
+#include <math.h>
+#include <pthread.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../../dc_sand_amd/csrc/bf_math.h"
+
+static inline uint32_t ulp_diff(float a, float b)
+{
+    if (a != a || b != b) return 0xffffffffu;
+    int64_t ia = (int64_t)(dcs_f32_bits(a) & 0x7fffffffu);
+    int64_t ib = (int64_t)(dcs_f32_bits(b) & 0x7fffffffu);
+    if (dcs_f32_bits(a) >> 31) ia = -ia;
+    if (dcs_f32_bits(b) >> 31) ib = -ib;
+    int64_t d = ia - ib;
+    if (d < 0) d = -d;
+    return d > 0xfffffffe ? 0xfffffffeu : (uint32_t)d;
+}
+
+struct sweep_job {
+    uint32_t lo, hi;     /* bit patterns [lo, hi) */
+    int variant;
+    float D, y;          /* div sweep */
+    uint32_t max_a, max_b;
+    uint64_t over_a, over_b;
+    uint32_t worst_a, worst_b;
+};
+
+static void *sincos_worker(void *arg)
+{
+    struct sweep_job *j = (struct sweep_job *)arg;
+    for (uint32_t u = j->lo; u < j->hi; u++) {
+        float x = dcs_bits_f32(u);
+        float s, c;
+        dcs_sincos_fast(x, &s, &c);
+        float es = (float)sin((double)x), ec = (float)cos((double)x);
+        uint32_t ds = ulp_diff(s, es), dc = ulp_diff(c, ec);
+        if (ds > j->max_a) { j->max_a = ds; j->worst_a = u; }
+        if (dc > j->max_b) { j->max_b = dc; j->worst_b = u; }
+        if (ds > 1) j->over_a++;
+        if (dc > 1) j->over_b++;
+    }
+    return NULL;
+}
+
+static void *div_worker(void *arg)
+{
+    struct sweep_job *j = (struct sweep_job *)arg;
+    for (uint32_t u = j->lo; u < j->hi; u++) {
+        float x = dcs_bits_f32(u);
+        float q = dcs_div_const(x, j->D, j->y);
+        volatile float xd = x, dd = j->D;
+        float e = xd / dd;
+        if (dcs_f32_bits(q) != dcs_f32_bits(e)) {
+            /* +0 vs -0 for x == -0 is tolerated by the callers (ULP metric);
+             * count it apart */
+            if (q == e) { j->over_b++; continue; }
+            j->over_a++;
+            if (j->max_a == 0) j->worst_a = u;
+            uint32_t d = ulp_diff(q, e);
+            if (d > j->max_a) j->max_a = d;
+        }
+    }
+    return NULL;
+}
+
+static void run_sweep(void *(*fn)(void *), struct sweep_job *proto, int nthreads,
+                      struct sweep_job *out)
+{
+    if (nthreads < 1) nthreads = 1;
+    struct sweep_job *jobs = (struct sweep_job *)calloc((size_t)nthreads, sizeof(*jobs));
+    pthread_t *th = (pthread_t *)calloc((size_t)nthreads, sizeof(*th));
+    uint64_t span = (uint64_t)proto->hi - proto->lo;
+    for (int i = 0; i < nthreads; i++) {
+        jobs[i] = *proto;
+        jobs[i].lo = proto->lo + (uint32_t)(span * (uint64_t)i / (uint64_t)nthreads);
+        jobs[i].hi = proto->lo + (uint32_t)(span * (uint64_t)(i + 1) / (uint64_t)nthreads);
+        pthread_create(&th[i], NULL, fn, &jobs[i]);
+    }
+    *out = *proto;
+    for (int i = 0; i < nthreads; i++) {
+        pthread_join(th[i], NULL);
+        if (jobs[i].max_a > out->max_a) { out->max_a = jobs[i].max_a; out->worst_a = jobs[i].worst_a; }
+        if (jobs[i].max_b > out->max_b) { out->max_b = jobs[i].max_b; out->worst_b = jobs[i].worst_b; }
+        out->over_a += jobs[i].over_a;
+        out->over_b += jobs[i].over_b;
+    }
+    free(jobs);
+    free(th);
+}
+
+extern "C" {
+
+/* Sweep every fp32 with bit pattern in [lo_bits, hi_bits) (positive floats:
+ * monotone in value).  res = {max_ulp_sin, max_ulp_cos, n_sin_over_1,
+ * n_cos_over_1, worst_x_bits_sin, worst_x_bits_cos}. */
+void lab_sincos_sweep(uint32_t lo_bits, uint32_t hi_bits, int nthreads, uint64_t *res)
+{
+    struct sweep_job p = {}, o;
+    p.lo = lo_bits;
+    p.hi = hi_bits;
+    run_sweep(sincos_worker, &p, nthreads, &o);
+    res[0] = o.max_a; res[1] = o.max_b; res[2] = o.over_a; res[3] = o.over_b;
+    res[4] = o.worst_a; res[5] = o.worst_b;
+}
+
+/* res = {n_mismatch, max_ulp, first_bad_x_bits, n_signed_zero_diffs} */
+void lab_div_sweep(float D, uint32_t lo_bits, uint32_t hi_bits, int nthreads, uint64_t *res)
+{
+    struct sweep_job p = {}, o;
+    p.lo = lo_bits;
+    p.hi = hi_bits;
+    p.D = D;
+    p.y = 1.0f / D;
+    run_sweep(div_worker, &p, nthreads, &o);
+    res[0] = o.over_a; res[1] = o.max_a; res[2] = o.worst_a; res[3] = o.over_b;
+}
+
+void lab_sincos(const float *x, size_t n, float *s, float *c)
+{
+    for (size_t i = 0; i < n; i++) dcs_sincos_fast(x[i], &s[i], &c[i]);
+}
+
+/* The device fast path, end to end, for one time step: out[c][i][2]. */
+void lab_generate_fast(const struct dcs_delay_vals *delays, size_t n_pairs,
+                       int32_t nr_channels, float sampling_period, float fDeltaTime,
+                       size_t c0, size_t nc, float *out, uint64_t *n_slow_pairs)
+{
+    const float D = sampling_period * nr_channels;
+    const float y = 1.0f / D;
+    const double half = nr_channels / 2.0;
+    uint64_t slow = 0;
+    for (size_t i = 0; i < n_pairs; i++) {
+        float k, p0;
+        dcs_pair_terms(delays[i], fDeltaTime, half, (double)D, &k, &p0);
+        if (!dcs_rate_in_fast_range(k)) slow++;
+        for (size_t c = c0; c < c0 + nc; c++) {
+            float rot = dcs_rotation(k, p0, (float)c, D, y);
+            float s, co;
+            if (fabsf(rot) < DCS_SINCOS_FAST_LIMIT && dcs_rate_in_fast_range(k)) {
+                dcs_sincos_fast(rot, &s, &co);
+            } else {
+                rot = dcs_rotation_ieee(k, p0, (float)c, D);
+                s = (float)sin((double)rot);
+                co = (float)cos((double)rot);
+            }
+            out[2 * ((c - c0) * n_pairs + i)] = co;
+            out[2 * ((c - c0) * n_pairs + i) + 1] = s;
+        }
+    }
+    if (n_slow_pairs) *n_slow_pairs = slow;
+}
+
+} // extern "C"
