@@ -75,13 +75,14 @@ SIGNATURES = [
     ("dcs_bf_set_delays_from_global", c_int, [_VP, _VP, c_uint32, c_uint32, _VP]),
     ("dcs_bf_generate", c_int, [_VP, c_int, c_int, c_uint64, c_uint32, _VP, c_size_t, _VP]),
     ("dcs_bf_generate_slab", c_int, [_VP, c_int, c_uint64, c_uint32, c_uint32, c_uint32, _VP, c_size_t, _VP]),
-    ("dcs_bf_set_tuning", c_int, [_VP, c_int, c_int, c_int]),
+    ("dcs_bf_set_tuning", c_int, [_VP, _VP]),
     ("dcs_bf_gpu_utilisation", c_int, [POINTER(CParams), c_float, POINTER(c_float)]),
     ("dcs_bf_stream_begin", c_int, [_VP, c_int, c_uint32, c_uint32, _VP, c_size_t, _VP, POINTER(_VP)]),
     ("dcs_bf_stream_tick", c_int, [_VP, c_uint64, _VP]),
     ("dcs_bf_stream_end", c_int, [_VP]),
     ("dcs_probe_sincos", c_int, [c_int, _VP, c_size_t, _VP, _VP, _VP]),
     ("dcs_probe_fill", c_int, [_VP, c_size_t, c_int, _VP]),
+    ("dcs_probe_store_pattern", c_int, [_VP, c_uint32, c_uint32, c_uint32, c_uint32, c_int, c_int, c_int, c_uint32, _VP]),
 ]
 
 _LIB = None

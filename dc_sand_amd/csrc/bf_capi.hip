@@ -74,11 +74,12 @@ struct dcs_bf_context {
     hipEvent_t dt_ev[kDtSlots];
     bool dt_used[kDtSlots];
     int dt_next;
-    // tuning
-    int chan_per_block;
-    int tiles_per_block;
-    int nontemporal;
-    int nomath;
+    // row-streaming form: per-(time step, pair) terms table + slow-path flags
+    uint32_t pairs_pad;     // n_pairs rounded up to 256
+    uint32_t terms_steps;   // time steps the table holds
+    float *d_terms;         // [terms_steps][pairs_pad][2]
+    uint32_t *d_flags;      // [terms_steps][pairs_pad/64]
+    dcs_bf_tuning tune;
 };
 
 struct dcs_bf_stream {
@@ -278,7 +279,15 @@ int dcs_bf_create(const dcs_bf_params *p, dcs_bf_context **out)
     c->p = *p;
     c->k = make_consts(p);
     c->n_pairs = (uint32_t)p->nr_stations * (uint32_t)p->nr_beams;
-    c->nontemporal = -1;
+    c->pairs_pad = (c->n_pairs + 255u) & ~255u;
+    {
+        const uint64_t per_step = (uint64_t)c->pairs_pad * 8u;
+        uint64_t steps = (64ull << 20) / per_step;
+        if (steps < 1) steps = 1;
+        if (steps > kDtSlotFloats) steps = kDtSlotFloats;
+        c->terms_steps = (uint32_t)steps;
+    }
+    c->tune.nontemporal = -1;
     int st = DCS_OK;
     do {
         if ((st = (int)hipGetDevice(&c->device)) != 0) break;
@@ -288,6 +297,8 @@ int dcs_bf_create(const dcs_bf_params *p, dcs_bf_context **out)
         const size_t db = (size_t)kDtSlots * kDtSlotFloats * sizeof(float);
         if ((st = (int)hipMalloc((void **)&c->d_dt, db)) != 0) break;
         if ((st = (int)hipHostMalloc((void **)&c->h_dt, db, hipHostMallocDefault)) != 0) break;
+        if ((st = (int)hipMalloc((void **)&c->d_terms, (size_t)c->terms_steps * c->pairs_pad * 8u)) != 0) break;
+        if ((st = (int)hipMalloc((void **)&c->d_flags, (size_t)c->terms_steps * (c->pairs_pad / 64u) * 4u)) != 0) break;
         for (int i = 0; i < kDtSlots && st == 0; i++) st = (int)hipEventCreateWithFlags(&c->dt_ev[i], hipEventDisableTiming);
     } while (0);
     if (st != 0) {
@@ -304,6 +315,8 @@ int dcs_bf_destroy(dcs_bf_context *c)
     (void)hipFree(c->d_table[0]);
     (void)hipFree(c->d_table[1]);
     (void)hipFree(c->d_dt);
+    (void)hipFree(c->d_terms);
+    (void)hipFree(c->d_flags);
     if (c->h_dt) (void)hipHostFree(c->h_dt);
     for (int i = 0; i < kDtSlots; i++)
         if (c->dt_ev[i]) (void)hipEventDestroy(c->dt_ev[i]);
@@ -337,42 +350,43 @@ int dcs_bf_set_delays_from_global(dcs_bf_context *c, const void *d_global, uint3
     return DCS_OK;
 }
 
-int dcs_bf_set_tuning(dcs_bf_context *c, int chan_per_block, int tiles_per_block, int nontemporal)
+int dcs_bf_set_tuning(dcs_bf_context *c, const dcs_bf_tuning *t)
 {
     if (!c) return DCS_ERR_INVALID_ARGUMENT;
-    const int nomath = (tiles_per_block & 0x100) ? 1 : 0; // probe: stores only
-    tiles_per_block &= 0xff;
-    if (chan_per_block < 0 || chan_per_block > (1 << 24)) return DCS_ERR_INVALID_ARGUMENT;
-    if (tiles_per_block != 0 && tiles_per_block != 1 && tiles_per_block != 2 && tiles_per_block != 4)
+    if (!t) { // back to the defaults
+        std::memset(&c->tune, 0, sizeof(c->tune));
+        c->tune.nontemporal = -1;
+        return DCS_OK;
+    }
+    if (t->form < 0 || t->form > 2) return DCS_ERR_INVALID_ARGUMENT;
+    if (t->nontemporal < -1 || t->nontemporal > 1) return DCS_ERR_INVALID_ARGUMENT;
+    if (t->chan_per_block < 0 || t->chan_per_block > (1 << 24)) return DCS_ERR_INVALID_ARGUMENT;
+    if (t->tiles_per_block != 0 && t->tiles_per_block != 1 && t->tiles_per_block != 2 && t->tiles_per_block != 4)
         return DCS_ERR_INVALID_ARGUMENT;
-    if (nontemporal < -1 || nontemporal > 1) return DCS_ERR_INVALID_ARGUMENT;
-    c->chan_per_block = chan_per_block;
-    c->tiles_per_block = tiles_per_block;
-    c->nontemporal = nontemporal;
-    c->nomath = nomath;
+    if (t->waves_per_block != 0 && t->waves_per_block != 4 && t->waves_per_block != 8 && t->waves_per_block != 16)
+        return DCS_ERR_INVALID_ARGUMENT;
+    if (t->rows_per_wave != 0 && t->rows_per_wave != 1 && t->rows_per_wave != 2 && t->rows_per_wave != 4)
+        return DCS_ERR_INVALID_ARGUMENT;
+    if (t->xcd_remap < -1 || t->xcd_remap > 1) return DCS_ERR_INVALID_ARGUMENT;
+    c->tune = *t;
     return DCS_OK;
 }
 
 namespace {
 
-// Defaults: see DESIGN.md "launch geometry".
+// Defaults: see DESIGN.md "launch geometry" (measured on MI355X at
+// 64 x 1024 x 32768, profiles/r01_geometry_sweep.md).  The write rate the HBM
+// system sustains falls with the number of stores a wave issues before it
+// retires, so the walk is kept SHORT: 4 channel rows per wave.
+//   fp32: 1 tile x 16 channels per workgroup (4 stores per wave), nontemporal;
+//   fp16: 4 tiles x 32 channels per workgroup (VALU-bound form).
 void pick_geometry(const dcs_bf_context *c, bool out16, uint32_t nc, uint32_t nt, int *tpb, uint32_t *cpb, bool *ntstore)
 {
-    *tpb = c->tiles_per_block ? c->tiles_per_block : 1;
-    *ntstore = c->nontemporal < 0 ? true : c->nontemporal != 0;
-    if (c->chan_per_block) {
-        *cpb = (uint32_t)c->chan_per_block;
-        return;
-    }
-    // Enough workgroups to fill 256 CUs x 8 several times over, but no fewer
-    // than 16 channels per wave so the per-workgroup fp64 set-up stays < 5 %.
-    const uint32_t ppl = out16 ? 4u : 2u;
-    const uint32_t pairs_per_block = 64u * ppl * (uint32_t)*tpb;
-    const uint64_t tile_groups = (c->n_pairs + pairs_per_block - 1) / pairs_per_block;
-    const uint32_t rows = 4u / (uint32_t)*tpb;
-    uint32_t cpb_v = 64u * rows; // 64 channels per wave
-    while (cpb_v > 16u * rows && tile_groups * ((nc + cpb_v - 1) / cpb_v) * nt < 8192u) cpb_v >>= 1;
-    *cpb = cpb_v;
+    (void)nc;
+    (void)nt;
+    *tpb = c->tune.tiles_per_block ? c->tune.tiles_per_block : (out16 ? 4 : 1);
+    *ntstore = c->tune.nontemporal < 0 ? true : c->tune.nontemporal != 0;
+    *cpb = c->tune.chan_per_block ? (uint32_t)c->tune.chan_per_block : (out16 ? 32u : 16u);
 }
 
 int launch_tiled(dcs_bf_context *c, bool out16, const float *dt_dev, float dt0, uint32_t nt, uint32_t c0,
@@ -394,7 +408,53 @@ int launch_tiled(dcs_bf_context *c, bool out16, const float *dt_dev, float dt0, 
     bool ntstore;
     pick_geometry(c, out16, nc, nt, &tpb, &cpb, &ntstore);
     a.chan_per_block = cpb;
-    return (int)bf_launch_tiled(a, out16, tpb | (c->nomath ? 0x100 : 0), ntstore, stream);
+    return (int)bf_launch_tiled(a, out16, tpb | (c->tune.nomath ? 0x100 : 0), ntstore, stream);
+}
+
+// Row-streaming form: terms pre-pass, then short waves in address order.
+int launch_rows(dcs_bf_context *c, bool out16, const float *dt_dev, float dt0, uint32_t nt, uint32_t c0,
+                uint32_t nc, void *d_out, hipStream_t stream)
+{
+    if (nt > c->terms_steps) return DCS_ERR_INVALID_ARGUMENT;
+    bf_terms_args ta;
+    std::memset(&ta, 0, sizeof(ta));
+    ta.delays = c->d_table[c->cur];
+    ta.terms = c->d_terms;
+    ta.flags = c->d_flags;
+    ta.dt_dev = dt_dev;
+    ta.dt0 = dt0;
+    ta.n_pairs = c->n_pairs;
+    ta.pairs_pad = c->pairs_pad;
+    ta.nt = nt;
+    ta.k = c->k;
+    hipError_t e = bf_launch_terms(ta, stream);
+    if (e != hipSuccess) return (int)e;
+    bf_rows_args a;
+    std::memset(&a, 0, sizeof(a));
+    a.terms = c->d_terms;
+    a.flags = c->d_flags;
+    a.out = d_out;
+    a.n_pairs = c->n_pairs;
+    a.pairs_pad = c->pairs_pad;
+    a.c0 = c0;
+    a.nc = nc;
+    a.nt = nt;
+    a.D = c->k.fDenominator;
+    a.y = c->k.fRcpDenominator;
+    const int nw = c->tune.waves_per_block ? c->tune.waves_per_block : 4;
+    const int rpw = c->tune.rows_per_wave ? c->tune.rows_per_wave : (out16 ? 4 : 2);
+    const bool ntstore = c->tune.nontemporal < 0 ? true : c->tune.nontemporal != 0;
+    const bool xcd = c->tune.xcd_remap < 0 ? true : c->tune.xcd_remap != 0;
+    return (int)bf_launch_rows(a, out16, nw, rpw, ntstore, xcd, c->tune.nomath != 0, stream);
+}
+
+// form 1 = tiled (long-lived waves), 2 = rows (short waves); 0 = library default
+int launch_form(dcs_bf_context *c, bool out16, const float *dt_dev, float dt0, uint32_t nt, uint32_t c0,
+                uint32_t nc, void *d_out, hipStream_t stream)
+{
+    const int form = c->tune.form ? c->tune.form : 1;
+    return form == 1 ? launch_tiled(c, out16, dt_dev, dt0, nt, c0, nc, d_out, stream)
+                     : launch_rows(c, out16, dt_dev, dt0, nt, c0, nc, d_out, stream);
 }
 
 // Stage dt[t0..t0+n) through a pinned slot into device memory on `stream`.
@@ -429,17 +489,18 @@ int dcs_bf_generate_slab(dcs_bf_context *c, int bitwidth, uint64_t t0, uint32_t 
     if (out_bytes < step_bytes * nt) return DCS_ERR_INVALID_ARGUMENT;
     hipStream_t s = as_stream(stream);
     for (uint32_t done = 0; done < nt;) {
-        const uint32_t n = (nt - done) < kDtSlotFloats ? (nt - done) : kDtSlotFloats;
+        uint32_t n = (nt - done) < kDtSlotFloats ? (nt - done) : kDtSlotFloats;
+        if (n > c->terms_steps) n = c->terms_steps;
         char *dst = static_cast<char *>(d_out) + (size_t)done * step_bytes;
         int st;
         if (n == 1) {
             float dt;
             if ((st = dcs_bf_delta_times(&c->p, t0 + done, 1, &dt)) != DCS_OK) return st;
-            st = launch_tiled(c, out16, nullptr, dt, 1, c0, nc, dst, s);
+            st = launch_form(c, out16, nullptr, dt, 1, c0, nc, dst, s);
         } else {
             const float *dt_dev = nullptr;
             if ((st = stage_dt(c, t0 + done, n, s, &dt_dev)) != DCS_OK) return st;
-            st = launch_tiled(c, out16, dt_dev, 0.0f, n, c0, nc, dst, s);
+            st = launch_form(c, out16, dt_dev, 0.0f, n, c0, nc, dst, s);
         }
         if (st != DCS_OK) return st;
         done += n;
@@ -544,7 +605,7 @@ int dcs_bf_stream_begin(dcs_bf_context *c, int bitwidth, uint32_t c0, uint32_t n
             c->cur = b;
             if ((st = (int)hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal)) != 0) break;
             st = (int)hipMemcpyAsync(s->d_dt, s->h_dt, sizeof(float), hipMemcpyHostToDevice, s->stream);
-            if (st == 0) st = launch_tiled(c, out16, s->d_dt, 0.0f, 1, c0, nc, d_out, s->stream);
+            if (st == 0) st = launch_form(c, out16, s->d_dt, 0.0f, 1, c0, nc, d_out, s->stream);
             hipGraph_t g = nullptr;
             const int st_end = (int)hipStreamEndCapture(s->stream, &g);
             if (st == 0) st = st_end;
@@ -617,6 +678,14 @@ int dcs_probe_fill(void *d_out, size_t bytes, int nontemporal, void *stream)
 {
     if (!d_out && bytes) return DCS_ERR_INVALID_ARGUMENT;
     return (int)bf_launch_probe_fill(d_out, bytes, nontemporal != 0, as_stream(stream));
+}
+
+int dcs_probe_store_pattern(void *d_out, uint32_t rows, uint32_t cols_kib, uint32_t qb, uint32_t rb, int order,
+                            int xcd_remap, int nontemporal, uint32_t block_threads, void *stream)
+{
+    if (!d_out) return DCS_ERR_INVALID_ARGUMENT;
+    return (int)bf_launch_probe_pattern(d_out, rows, cols_kib, qb, rb, (uint32_t)order, (uint32_t)xcd_remap,
+                                        nontemporal != 0, block_threads, as_stream(stream));
 }
 
 } // extern "C"

@@ -28,6 +28,32 @@ struct bf_tiled_args {
 hipError_t bf_launch_tiled(const bf_tiled_args &a, bool out16, int tiles_per_block,
                            bool nontemporal, hipStream_t stream);
 
+// Row-streaming form: a terms table written by bf_launch_terms, then one short
+// wave per (1-KiB tile, rows_per_wave channel rows).
+struct bf_terms_args {
+    const dcs_delay_vals *delays; // [n_pairs]
+    float *terms;                 // [nt][pairs_pad][2]
+    uint32_t *flags;              // [nt][pairs_pad/64]
+    const float *dt_dev;          // or nullptr -> dt0, nt == 1
+    float dt0;
+    uint32_t n_pairs, pairs_pad, nt;
+    dcs_bf_consts k;
+};
+hipError_t bf_launch_terms(const bf_terms_args &a, hipStream_t stream);
+
+struct bf_rows_args {
+    const float *terms;
+    const uint32_t *flags;
+    void *out; // [nt][nc][n_pairs]
+    uint32_t n_pairs, pairs_pad;
+    uint32_t c0, nc, nt;
+    uint32_t n_colgroups, n_rowgroups; // filled by the launcher
+    uint32_t xcd_remap;
+    float D, y;
+};
+hipError_t bf_launch_rows(const bf_rows_args &a, bool out16, int waves_per_block, int rows_per_wave,
+                          bool nontemporal, bool xcd_remap, bool nomath, hipStream_t stream);
+
 // One coefficient per lane, one time step (reference kernel a1's shape).
 struct bf_naive_args {
     const dcs_delay_vals *delays;
@@ -47,5 +73,8 @@ hipError_t bf_launch_gather_beams(dcs_delay_vals *local, const dcs_delay_vals *g
 hipError_t bf_launch_probe_sincos(int which, const float *x, size_t n, float *s, float *c,
                                   hipStream_t stream);
 hipError_t bf_launch_probe_fill(void *out, size_t bytes, bool nontemporal, hipStream_t stream);
+hipError_t bf_launch_probe_pattern(void *out, uint32_t rows, uint32_t cols, uint32_t QB, uint32_t RB,
+                                   uint32_t order, uint32_t xcd, bool nontemporal, uint32_t block_threads,
+                                   hipStream_t stream);
 
 #endif

@@ -215,6 +215,146 @@ __global__ void __launch_bounds__(kBlock) bf_tiled_kernel(const bf_tiled_args a)
 }
 
 // ---------------------------------------------------------------------------
+// Row-streaming generator ("rows" form): the form the HBM system likes best.
+//
+// tools/explore_patterns.py (profiles/r01_store_patterns.md) shows that the
+// write rate MI355X sustains depends on how long a wave keeps storing: waves
+// that issue 1 / 2 / 4 stores and retire, dispatched in address order, reach
+// 7.1 / 6.9 / 6.6 TB/s; waves that walk hundreds of rows reach 5.5 TB/s.  So
+// here a wave owns ONE 1-KiB tile of RPW consecutive channel rows and retires;
+// workgroups are numbered column-fastest so the dispatcher itself streams the
+// tensor in address order.  The channel-independent terms of every pair come
+// from a small table ({fRateTerm, fPhase0} per pair and time step, written by
+// bf_terms_kernel just before; L2-resident: 8 B per pair against 8*C B of
+// output), one 16-byte load per lane.
+//   NW   : waves per workgroup = adjacent 1-KiB tiles of one row (4, 8, 16)
+//   RPW  : consecutive channel rows per wave (1, 2, 4)
+// ---------------------------------------------------------------------------
+template <bool OUT16, int NW, int RPW, bool NT, bool ALIGNED, bool NOMATH>
+__global__ void __launch_bounds__(NW * 64) bf_rows_kernel(const bf_rows_args a)
+{
+    constexpr int PPL = OUT16 ? 4 : 2;
+    constexpr int TILE = 64 * PPL;
+    constexpr uint32_t EB = OUT16 ? 4u : 8u;
+
+    uint32_t b = blockIdx.x;
+    if (a.xcd_remap) b = (b % 8u) * (gridDim.x / 8u) + b / 8u; // gridDim.x % 8 == 0 (host)
+    const uint32_t cg = b % a.n_colgroups;
+    const uint32_t rg = b / a.n_colgroups;
+    const uint32_t t = rg / a.n_rowgroups;
+    const uint32_t c = (rg - t * a.n_rowgroups) * (uint32_t)RPW; // channel within the slab
+
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t chunk = cg * (uint32_t)NW + wave;
+    if (chunk * (uint32_t)TILE >= a.n_pairs) return; // wave-uniform
+    const uint32_t p0 = chunk * (uint32_t)TILE + lane * PPL;
+
+    // slow-path flags of this wave's pairs: one dword per 64 pairs (scalar loads)
+    const uint32_t *fl = a.flags + (uint64_t)t * (a.pairs_pad / 64u) + chunk * (uint32_t)(TILE / 64);
+    uint32_t slow = 0;
+#pragma unroll
+    for (int j = 0; j < TILE / 64; j++) slow |= fl[j];
+
+    float fRate[PPL], fPhase0[PPL];
+    const floatx4 *tp = reinterpret_cast<const floatx4 *>(a.terms + 2u * ((uint64_t)t * a.pairs_pad + p0));
+#pragma unroll
+    for (int j = 0; j < PPL; j += 2) {
+        const floatx4 v = tp[j / 2];
+        fRate[j] = v.x;
+        fPhase0[j] = v.y;
+        fRate[j + 1] = v.z;
+        fPhase0[j + 1] = v.w;
+    }
+    if (p0 >= a.n_pairs) return;
+
+    const float D = a.D, y = a.y;
+    const uint64_t row_bytes = (uint64_t)a.n_pairs * EB;
+    char *dst = reinterpret_cast<char *>(a.out) + ((uint64_t)t * a.nc + c) * row_bytes + (uint64_t)p0 * EB;
+
+    auto emit = [&](const float (&re)[PPL], const float (&im)[PPL]) {
+        if constexpr (ALIGNED) {
+            if constexpr (OUT16) {
+                uintx4 v;
+                v.x = pack_half2(re[0], im[0]);
+                v.y = pack_half2(re[1], im[1]);
+                v.z = pack_half2(re[2], im[2]);
+                v.w = pack_half2(re[3], im[3]);
+                store_global<NT>(reinterpret_cast<uintx4 *>(dst), v);
+            } else {
+                store_global<NT>(reinterpret_cast<floatx4 *>(dst), floatx4{re[0], im[0], re[1], im[1]});
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < PPL; j++) {
+                if (p0 + j < a.n_pairs) {
+                    if constexpr (OUT16)
+                        store_global<NT>(reinterpret_cast<uint32_t *>(dst) + j, pack_half2(re[j], im[j]));
+                    else
+                        store_global<NT>(reinterpret_cast<floatx2 *>(dst) + j, floatx2{re[j], im[j]});
+                }
+            }
+        }
+    };
+
+    if (__builtin_expect(slow == 0u, 1)) {
+#pragma unroll
+        for (int r = 0; r < RPW; r++) {
+            if (c + r < a.nc) {
+                const float fChan = (float)(a.c0 + c + r);
+                float re[PPL], im[PPL];
+#pragma unroll
+                for (int j = 0; j < PPL; j++) {
+                    if constexpr (NOMATH) {
+                        re[j] = fRate[j];
+                        im[j] = fPhase0[j] + fChan;
+                    } else {
+                        coeff_fast(fRate[j], fPhase0[j], fChan, D, y, re[j], im[j]);
+                    }
+                }
+                emit(re, im);
+                dst += row_bytes;
+            }
+        }
+    } else {
+        for (int r = 0; r < RPW; r++) {
+            if (c + r < a.nc) {
+                const float fChan = (float)(a.c0 + c + r);
+                float re[PPL], im[PPL];
+#pragma unroll 1
+                for (int j = 0; j < PPL; j++) coeff_slow(fRate[j], fPhase0[j], fChan, D, re[j], im[j]);
+                emit(re, im);
+                dst += row_bytes;
+            }
+        }
+    }
+}
+
+// terms[t][p] = {fRateTerm, fPhase0}; flags[t][p/64] != 0 iff any of those 64
+// pairs must take the slow path.  p runs to pairs_pad (a multiple of 256);
+// pairs past n_pairs get zeros.  One lane per (t, p); 64 lanes = one flag word.
+__global__ void __launch_bounds__(kBlock) bf_terms_kernel(const bf_terms_args a)
+{
+    const uint32_t p = blockIdx.x * kBlock + threadIdx.x; // < pairs_pad (grid exact)
+    const uint32_t t = blockIdx.y;
+    const float dt = a.dt_dev ? a.dt_dev[t] : a.dt0;
+    float fRate = 0.0f, fPhase0 = 0.0f;
+    if (p < a.n_pairs) {
+        const floatx4 raw = *reinterpret_cast<const floatx4 *>(&a.delays[p]);
+        dcs_delay_vals d;
+        d.fDelay_s = raw.x;
+        d.fDelayRate_sps = raw.y;
+        d.fPhase_rad = raw.z;
+        d.fPhaseRate_radps = raw.w;
+        dcs_pair_terms(d, dt, a.k.dHalfChannels, a.k.dDenominator, &fRate, &fPhase0);
+    }
+    const bool slow = !dcs_pair_is_fast(fRate, fPhase0, a.k.fRotBoundScale);
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(slow);
+    *reinterpret_cast<floatx2 *>(a.terms + 2u * ((uint64_t)t * a.pairs_pad + p)) = floatx2{fRate, fPhase0};
+    if ((threadIdx.x & 63u) == 0u) a.flags[(uint64_t)t * (a.pairs_pad / 64u) + p / 64u] = (m != 0ull) ? 1u : 0u;
+}
+
+// ---------------------------------------------------------------------------
 // One coefficient per lane (the launch shape of the reference's
 // calculate_beamweights_naive, BeamformerKernels.cu:7-52): every lane redoes the
 // per-pair terms.  grid = (ceil(n_pairs/256), min(nc, 65535)).
@@ -283,6 +423,39 @@ __global__ void __launch_bounds__(kBlock) bf_probe_fill_kernel(uintx4 *out, size
     const uintx4 v = {0x3f800000u, 0u, 0x3f800000u, 0u};
     for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n16; i += (size_t)gridDim.x * kBlock)
         store_global<NT>(out + i, v);
+}
+
+// Store-pattern probe: the output seen as `rows` x `cols` chunks of 1 KiB (one
+// wave store each).  A workgroup owns a rectangle of RB rows x QB chunks; its 4
+// waves take the rectangle's chunks round-robin, chunk k -> (row k / QB,
+// col k % QB).  Rectangles are numbered column-fastest (order 0) or row-fastest
+// (order 1); xcd != 0 renumbers workgroups so that those sharing b % 8 (one
+// XCD under round-robin dispatch) own consecutive rectangles.  No arithmetic.
+template <bool NT>
+__global__ void __launch_bounds__(1024) bf_probe_pattern_kernel(uintx4 *out, uint32_t rows, uint32_t cols,
+                                                                  uint32_t QB, uint32_t RB, uint32_t order,
+                                                                  uint32_t xcd)
+{
+    const uint32_t nq = (cols + QB - 1) / QB, nr = (rows + RB - 1) / RB;
+    uint32_t b = blockIdx.x;
+    const uint32_t G = gridDim.x;
+    if (xcd && (G % 8u) == 0u) b = (b % 8u) * (G / 8u) + b / 8u;
+    uint32_t rq, rr;
+    if (order == 0) {
+        rq = b % nq;
+        rr = b / nq;
+    } else {
+        rr = b % nr;
+        rq = b / nr;
+    }
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uintx4 v = {0x3f800000u, b, 0x3f800000u, lane};
+    const uint32_t nk = QB * RB;
+    const uint32_t nwaves = blockDim.x >> 6;
+    for (uint32_t k = wave; k < nk; k += nwaves) {
+        const uint32_t r = rr * RB + k / QB, q = rq * QB + k % QB;
+        if (r < rows && q < cols) store_global<NT>(out + ((uint64_t)r * cols + q) * 64u + lane, v);
+    }
 }
 
 template <bool OUT16, int TPB, bool NT, bool ALIGNED>
@@ -381,4 +554,95 @@ hipError_t bf_launch_probe_fill(void *out, size_t bytes, bool nontemporal, hipSt
         hipLaunchKernelGGL(bf_probe_fill_kernel<false>, grid, dim3(kBlock), 0, stream,
                            reinterpret_cast<uintx4 *>(out), n16);
     return hipGetLastError();
+}
+
+hipError_t bf_launch_probe_pattern(void *out, uint32_t rows, uint32_t cols, uint32_t QB, uint32_t RB,
+                                   uint32_t order, uint32_t xcd, bool nontemporal, uint32_t block_threads,
+                                   hipStream_t stream)
+{
+    if (!rows || !cols || !QB || !RB) return hipErrorInvalidValue;
+    if (block_threads == 0) block_threads = kBlock;
+    if (block_threads % 64u || block_threads > 1024u) return hipErrorInvalidValue;
+    const uint64_t nblk = (uint64_t)((cols + QB - 1) / QB) * ((rows + RB - 1) / RB);
+    if (nblk > 0x7fffffffull) return hipErrorInvalidValue;
+    const dim3 grid((uint32_t)nblk);
+    if (nontemporal)
+        hipLaunchKernelGGL(bf_probe_pattern_kernel<true>, grid, dim3(block_threads), 0, stream,
+                           reinterpret_cast<uintx4 *>(out), rows, cols, QB, RB, order, xcd);
+    else
+        hipLaunchKernelGGL(bf_probe_pattern_kernel<false>, grid, dim3(block_threads), 0, stream,
+                           reinterpret_cast<uintx4 *>(out), rows, cols, QB, RB, order, xcd);
+    return hipGetLastError();
+}
+
+namespace {
+
+template <bool OUT16, int NW, int RPW>
+hipError_t launch_rows_t(const bf_rows_args &a, bool nt, bool aligned, bool nomath, dim3 grid, hipStream_t stream)
+{
+#define DCS_ROWS_LAUNCH(NTV, ALV, NMV)                                                                       \
+    hipLaunchKernelGGL((bf_rows_kernel<OUT16, NW, RPW, NTV, ALV, NMV>), grid, dim3(NW * 64), 0, stream, a)
+    if (nomath) {
+        if (nt) { if (aligned) DCS_ROWS_LAUNCH(true, true, true); else DCS_ROWS_LAUNCH(true, false, true); }
+        else    { if (aligned) DCS_ROWS_LAUNCH(false, true, true); else DCS_ROWS_LAUNCH(false, false, true); }
+    } else {
+        if (nt) { if (aligned) DCS_ROWS_LAUNCH(true, true, false); else DCS_ROWS_LAUNCH(true, false, false); }
+        else    { if (aligned) DCS_ROWS_LAUNCH(false, true, false); else DCS_ROWS_LAUNCH(false, false, false); }
+    }
+#undef DCS_ROWS_LAUNCH
+    return hipGetLastError();
+}
+
+template <bool OUT16, int NW>
+hipError_t launch_rows_w(const bf_rows_args &a, int rpw, bool nt, bool aligned, bool nomath, dim3 grid,
+                         hipStream_t stream)
+{
+    switch (rpw) {
+    case 1: return launch_rows_t<OUT16, NW, 1>(a, nt, aligned, nomath, grid, stream);
+    case 2: return launch_rows_t<OUT16, NW, 2>(a, nt, aligned, nomath, grid, stream);
+    case 4: return launch_rows_t<OUT16, NW, 4>(a, nt, aligned, nomath, grid, stream);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+template <bool OUT16>
+hipError_t launch_rows_o(const bf_rows_args &a, int nw, int rpw, bool nt, bool aligned, bool nomath, dim3 grid,
+                         hipStream_t stream)
+{
+    switch (nw) {
+    case 4: return launch_rows_w<OUT16, 4>(a, rpw, nt, aligned, nomath, grid, stream);
+    case 8: return launch_rows_w<OUT16, 8>(a, rpw, nt, aligned, nomath, grid, stream);
+    case 16: return launch_rows_w<OUT16, 16>(a, rpw, nt, aligned, nomath, grid, stream);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+} // namespace
+
+hipError_t bf_launch_terms(const bf_terms_args &a, hipStream_t stream)
+{
+    if (a.nt == 0 || a.pairs_pad == 0) return hipSuccess;
+    if (a.pairs_pad % kBlock || a.nt > 65535u) return hipErrorInvalidValue;
+    if (a.dt_dev == nullptr && a.nt != 1) return hipErrorInvalidValue;
+    const dim3 grid(a.pairs_pad / kBlock, a.nt);
+    hipLaunchKernelGGL(bf_terms_kernel, grid, dim3(kBlock), 0, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t bf_launch_rows(const bf_rows_args &a_in, bool out16, int waves_per_block, int rows_per_wave,
+                          bool nontemporal, bool xcd_remap, bool nomath, hipStream_t stream)
+{
+    bf_rows_args a = a_in;
+    if (a.n_pairs == 0 || a.nc == 0 || a.nt == 0) return hipSuccess;
+    const uint32_t ppl = out16 ? 4u : 2u;
+    const uint32_t cols = 64u * ppl * (uint32_t)waves_per_block;
+    a.n_colgroups = (a.n_pairs + cols - 1) / cols;
+    a.n_rowgroups = (a.nc + (uint32_t)rows_per_wave - 1) / (uint32_t)rows_per_wave;
+    const uint64_t blocks = (uint64_t)a.n_colgroups * a.n_rowgroups * a.nt;
+    if (blocks == 0 || blocks > 0x7fffffffull) return hipErrorInvalidValue;
+    a.xcd_remap = (xcd_remap && (blocks % 8u) == 0u) ? 1u : 0u;
+    const bool aligned = (a.n_pairs % ppl) == 0 && (reinterpret_cast<uintptr_t>(a.out) % 16u) == 0;
+    const dim3 grid((uint32_t)blocks);
+    return out16 ? launch_rows_o<true>(a, waves_per_block, rows_per_wave, nontemporal, aligned, nomath, grid, stream)
+                 : launch_rows_o<false>(a, waves_per_block, rows_per_wave, nontemporal, aligned, nomath, grid, stream);
 }

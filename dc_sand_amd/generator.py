@@ -99,12 +99,12 @@ class SteeringCoefficientGenerator:
             "dcs_bf_generate_slab",
         )
 
-    def set_tuning(self, chan_per_block: int = 0, tiles_per_block: int = 0, nontemporal: int = -1, nomath: bool = False) -> None:
-        check(
-            _lib.lib().dcs_bf_set_tuning(c_void_p(self._h), int(chan_per_block), int(tiles_per_block) | (0x100 if nomath else 0),
-                                         int(nontemporal)),
-            "dcs_bf_set_tuning",
-        )
+    def set_tuning(self, form: int = 0, nontemporal: int = -1, chan_per_block: int = 0, tiles_per_block: int = 0,
+                   waves_per_block: int = 0, rows_per_wave: int = 0, xcd_remap: int = -1, nomath: bool = False) -> None:
+        """``struct dcs_bf_tuning``; ``set_tuning()`` restores the defaults."""
+        t = (ctypes.c_int32 * 8)(form, nontemporal, chan_per_block, tiles_per_block, waves_per_block, rows_per_wave,
+                                 xcd_remap, 1 if nomath else 0)
+        check(_lib.lib().dcs_bf_set_tuning(c_void_p(self._h), ctypes.cast(t, c_void_p)), "dcs_bf_set_tuning")
 
     def output_bytes(self, bitwidth: int = B32, nt: int = 1) -> int:
         return output_bytes(self.params, bitwidth, nt)

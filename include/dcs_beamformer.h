@@ -161,9 +161,26 @@ int dcs_bf_generate(dcs_bf_context *ctx, int kernel, int bitwidth, uint64_t t0, 
 int dcs_bf_generate_slab(dcs_bf_context *ctx, int bitwidth, uint64_t t0, uint32_t nt,
                          uint32_t c0, uint32_t nc, void *d_out, size_t out_bytes, void *stream);
 
-/* Tuning knobs (0 = library default): channels per workgroup, 128-pair tiles
- * per workgroup (1, 2 or 4), nontemporal stores (0/1; -1 = default). */
-int dcs_bf_set_tuning(dcs_bf_context *ctx, int chan_per_block, int tiles_per_block, int nontemporal);
+/* Launch-geometry knobs (all 0 / NULL = library defaults; DESIGN.md "launch
+ * geometry").  Two forms of the MULTIPLE_CHANNELS_AND_TIMESTAMPS generator
+ * exist and give identical bits:
+ *   form 1 "tiled": a workgroup keeps its pairs' terms in registers and walks
+ *           chan_per_block channels (tiles_per_block 1-KiB tiles wide);
+ *   form 2 "rows":  a small terms table is written first, then short waves
+ *           (waves_per_block adjacent 1-KiB tiles x rows_per_wave channel rows)
+ *           stream the tensor in address order -- the form HBM sustains best.
+ * MULTIPLE_CHANNELS always uses form 1 (the reference's per-time-step shape). */
+struct dcs_bf_tuning {
+    int32_t form;            /* 0 default, 1 tiled, 2 rows */
+    int32_t nontemporal;     /* -1 default, 0 plain stores, 1 nontemporal */
+    int32_t chan_per_block;  /* form 1 */
+    int32_t tiles_per_block; /* form 1: 1, 2, 4 */
+    int32_t waves_per_block; /* form 2: 4, 8, 16 */
+    int32_t rows_per_wave;   /* form 2: 1, 2, 4 */
+    int32_t xcd_remap;       /* form 2: -1 default, 0, 1 */
+    int32_t nomath;          /* probe: addressing and stores only */
+};
+int dcs_bf_set_tuning(dcs_bf_context *ctx, const struct dcs_bf_tuning *t);
 
 /* get_time(), BCT.cu:422-454: the real-time utilisation model, from a kernel
  * duration in ms.  out[0] = per single time unit, out[1] = per
@@ -188,6 +205,11 @@ int dcs_probe_sincos(int which, const float *d_x, size_t n, float *d_sin, float 
 /* Pure store kernel with the generator's access pattern and no arithmetic: the
  * measured HBM-write ceiling the roofline fraction is read against. */
 int dcs_probe_fill(void *d_out, size_t bytes, int nontemporal, void *stream);
+/* Store-only kernel over a `rows` x `cols_kib` KiB matrix: each workgroup owns a
+ * rectangle of rb rows x qb KiB (tools/explore.py maps out which write patterns
+ * the HBM system sustains; see DESIGN.md "write patterns"). */
+int dcs_probe_store_pattern(void *d_out, uint32_t rows, uint32_t cols_kib, uint32_t qb, uint32_t rb, int order,
+                            int xcd_remap, int nontemporal, uint32_t block_threads, void *stream);
 
 #ifdef __cplusplus
 }

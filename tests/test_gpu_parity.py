@@ -1,0 +1,298 @@
+"""GPU parity: the HIP path, called through the C-ABI, against the CPU oracle.
+
+Bar: every fp32 element within 1 ULP of the oracle (ordered-integer distance of
+the bit patterns), and the reference's own rule |gpu - cpu| <= 1e-4
+(runBeamformerTests.cpp:30,61).  Time indices 5, 7, 9, 18 are those where the
+reference's three dt derivations disagree.
+"""
+import numpy as np
+import pytest
+
+from conftest import rand_table
+
+pytestmark = pytest.mark.gpu
+
+PARITY_T = [0, 1, 5, 7, 9, 18, 255]
+
+
+def _gen(gpu, bp, table, t0, nt, kernel=2, bitwidth=1, c0=None, nc=None, tuning=None):
+    from dc_sand_amd.generator import SteeringCoefficientGenerator
+
+    g = SteeringCoefficientGenerator(bp)
+    if tuning:
+        g.set_tuning(**tuning)
+    g.upload_delays(table)
+    eb = 4 if bitwidth == 0 else 8
+    if c0 is None:
+        nbytes = nt * bp.NR_CHANNELS * bp.n_pairs * eb
+        shape = (nt, bp.NR_CHANNELS, bp.NR_STATIONS, bp.NR_BEAMS, 2)
+    else:
+        nbytes = nt * nc * bp.n_pairs * eb
+        shape = (nt, nc, bp.NR_STATIONS, bp.NR_BEAMS, 2)
+    buf = gpu.mem_alloc(nbytes + 256)
+    gpu.memset(buf, 0xFF, nbytes + 256)  # NaN canary, also past the end
+    if c0 is None:
+        g.generate(buf, nbytes, t0=t0, nt=nt, kernel=kernel, bitwidth=bitwidth)
+    else:
+        g.generate_slab(buf, nbytes, c0, nc, t0=t0, nt=nt, bitwidth=bitwidth)
+    host = np.empty(nbytes + 256, dtype=np.uint8)
+    gpu.memcpy_dtoh(host, buf)
+    assert np.all(host[nbytes:] == 0xFF), "wrote past the end of the output tensor"
+    dt = np.float16 if bitwidth == 0 else np.float32
+    out = host[:nbytes].view(dt).reshape(shape)
+    g.close()
+    buf.free()
+    return out
+
+
+def _check(oracle, got, exp, tol=1e-4):
+    mx, n_over, first = oracle.max_ulp(got, exp, 1)
+    assert n_over == 0, f"max ULP {mx}, {n_over} elements over 1 ULP, first flat index {first}"
+    assert oracle.compare(got, exp, tol) == -1
+    return mx
+
+
+@pytest.mark.parametrize("kernel", [0, 1, 2])
+def test_config1_4ant_2beam_1024chan(gpu, oracle, kernel):
+    """BASELINE configs[0]: 4 ant x 2 beam x 1024 chan, reference ramp input."""
+    from dc_sand_amd import BeamformerParameters
+    from dc_sand_amd.generator import simulate_input
+
+    bp = BeamformerParameters(NR_CHANNELS=1024, NR_STATIONS=4, NR_BEAMS=2)
+    table = simulate_input(bp)
+    op = oracle.params_from(bp)
+    assert np.array_equal(table.view(np.uint32), oracle.simulate_input(op).view(np.uint32))
+    for t in PARITY_T:
+        got = _gen(gpu, bp, table, t, 1, kernel=kernel)
+        _check(oracle, got, oracle.generate(op, table, t, 1))
+
+
+@pytest.mark.parametrize("kernel", [0, 1, 2])
+def test_reference_default_shape_all_256_time_steps(gpu, oracle, kernel):
+    """BeamformerParameters.h defaults (64 chan, 64 ant, 16 beams, 256 samples):
+    the tensor runBeamformerTests verifies, every element."""
+    from dc_sand_amd import BeamformerParameters
+    from dc_sand_amd.generator import simulate_input
+
+    bp = BeamformerParameters()
+    table = simulate_input(bp)
+    op = oracle.params_from(bp)
+    got = _gen(gpu, bp, table, 0, 256, kernel=kernel)
+    _check(oracle, got, oracle.generate(op, table, 0, 256))
+
+
+@pytest.mark.parametrize("seeded", [False, True])
+def test_config2_64ant_64beam_4096chan(gpu, oracle, seeded):
+    """BASELINE configs[1]: single launch, every element compared."""
+    from dc_sand_amd import BeamformerParameters
+    from dc_sand_amd.generator import simulate_input
+
+    bp = BeamformerParameters(NR_CHANNELS=4096, NR_STATIONS=64, NR_BEAMS=64)
+    table = rand_table(bp.n_pairs) if seeded else simulate_input(bp)
+    op = oracle.params_from(bp)
+    for t in (1, 9):
+        got = _gen(gpu, bp, table, t, 1)
+        _check(oracle, got, oracle.generate(op, table, t, 1))
+
+
+TUNINGS = [
+    dict(form=1, tiles_per_block=1, nontemporal=1),
+    dict(form=1, tiles_per_block=2, nontemporal=0),
+    dict(form=1, tiles_per_block=4, chan_per_block=8, nontemporal=1),
+    dict(form=1, tiles_per_block=1, chan_per_block=3),
+    dict(form=1, tiles_per_block=4, chan_per_block=1000),
+    dict(form=2, waves_per_block=4, rows_per_wave=1),
+    dict(form=2, waves_per_block=4, rows_per_wave=2, nontemporal=1),
+    dict(form=2, waves_per_block=8, rows_per_wave=4, xcd_remap=1),
+    dict(form=2, waves_per_block=16, rows_per_wave=1, xcd_remap=1, nontemporal=1),
+    dict(form=2, waves_per_block=16, rows_per_wave=4),
+]
+
+
+@pytest.mark.parametrize("tuning", TUNINGS, ids=lambda d: "-".join(f"{k}{v}" for k, v in d.items()))
+@pytest.mark.parametrize("bitwidth", [1, 0])
+def test_tunings_agree(gpu, oracle, tuning, bitwidth):
+    """Every form and launch geometry gives the same bits (ragged channel
+    blocks, partial tiles and odd row groups included)."""
+    from dc_sand_amd import BeamformerParameters
+
+    for (A, B, C) in ((7, 38, 301), (3, 5, 17), (64, 16, 64)):
+        bp = BeamformerParameters(NR_CHANNELS=C, NR_STATIONS=A, NR_BEAMS=B)
+        table = rand_table(bp.n_pairs, seed=7)
+        op = oracle.params_from(bp)
+        got = _gen(gpu, bp, table, 3, 3, tuning=tuning, bitwidth=bitwidth)
+        exp = oracle.generate(op, table, 3, 3)
+        if bitwidth == 1:
+            _check(oracle, got, exp)
+        else:
+            base = _gen(gpu, bp, table, 3, 3, bitwidth=0)
+            assert np.array_equal(got.view(np.uint16), base.view(np.uint16))
+
+
+@pytest.mark.parametrize("A,B,C", [(1, 1, 1), (3, 5, 17), (5, 3, 64), (1, 129, 33), (64, 1, 5), (2, 257, 9)])
+@pytest.mark.parametrize("kernel", [0, 1, 2])
+def test_ragged_and_odd_shapes(gpu, oracle, A, B, C, kernel):
+    """Odd pair counts (8-byte stores), partial tiles, single elements; the
+    three kernel options cover the naive, tiled and rows forms."""
+    from dc_sand_amd import BeamformerParameters
+
+    bp = BeamformerParameters(NR_CHANNELS=C, NR_STATIONS=A, NR_BEAMS=B)
+    table = rand_table(bp.n_pairs, seed=A * 1000 + B)
+    op = oracle.params_from(bp)
+    got = _gen(gpu, bp, table, 7, 3, kernel=kernel)
+    _check(oracle, got, oracle.generate(op, table, 7, 3))
+
+
+def test_channel_slab(gpu, oracle):
+    from dc_sand_amd import BeamformerParameters
+
+    bp = BeamformerParameters(NR_CHANNELS=32768, NR_STATIONS=4, NR_BEAMS=32)
+    table = rand_table(bp.n_pairs, seed=11)
+    op = oracle.params_from(bp)
+    for c0, nc in ((0, 5), (32000, 768), (16383, 2)):
+        got = _gen(gpu, bp, table, 18, 2, c0=c0, nc=nc)
+        _check(oracle, got, oracle.generate(op, table, 18, 2, c0, nc))
+
+
+def test_slow_path_large_rotation_and_extreme_rates(gpu, oracle):
+    """Pairs outside the fast path's proven range (|rotation| >= 32000, tiny or
+    huge rate terms, zero rate) take the IEEE-divide + fp64-sincos branch."""
+    from dc_sand_amd import BeamformerParameters
+
+    bp = BeamformerParameters(NR_CHANNELS=512, NR_STATIONS=2, NR_BEAMS=128)
+    table = rand_table(bp.n_pairs, seed=3)
+    table["fDelayRate_sps"][5] = 1e-2      # rotation up to ~3e5 rad
+    table["fDelayRate_sps"][6] = 1e-30     # below dcs_div_const's range
+    table["fDelayRate_sps"][7] = 0.0
+    table["fPhase_rad"][130] = 5e4
+    table["fDelayRate_sps"][200] = -3.0    # huge
+    table["fDelay_s"][201] = 1.0
+    op = oracle.params_from(bp)
+    for t in (0, 9):
+        for form in (1, 2):
+            got = _gen(gpu, bp, table, t, 1, tuning=dict(form=form))
+            _check(oracle, got, oracle.generate(op, table, t, 1), tol=1e-4)
+
+
+def test_fp16_output(gpu, oracle):
+    """b16: packed half2, RN-even of the fp32 coefficient.  The reference never
+    verifies this mode (BeamformerCoefficientTest.cu:282-287): parity unpinned;
+    the expectation is RN-even(oracle fp32), tolerance 1 half-ULP."""
+    from dc_sand_amd import BeamformerParameters
+
+    for (A, B, C) in ((64, 16, 64), (3, 5, 17), (2, 130, 9)):
+        bp = BeamformerParameters(NR_CHANNELS=C, NR_STATIONS=A, NR_BEAMS=B)
+        table = rand_table(bp.n_pairs, seed=5)
+        op = oracle.params_from(bp)
+        got = _gen(gpu, bp, table, 5, 2, kernel=2, bitwidth=0)
+        exp = oracle.generate(op, table, 5, 2).astype(np.float16)
+        gi = got.view(np.int16).astype(np.int32)
+        ei = exp.view(np.int16).astype(np.int32)
+        gi = np.where(gi < 0, -(gi & 0x7FFF), gi)
+        ei = np.where(ei < 0, -(ei & 0x7FFF), ei)
+        assert np.max(np.abs(gi - ei)) <= 1
+        # MULTIPLE_CHANNELS supports b16 as well (reference kernel a2)
+        got2 = _gen(gpu, bp, table, 5, 2, kernel=1, bitwidth=0)
+        assert np.array_equal(got.view(np.uint16), got2.view(np.uint16))
+
+
+def test_error_behaviour(gpu):
+    """NAIVE + b16 and COMBINED are refused like the reference's ctor throws
+    (BeamformerCoefficientTest.cu:40-50); generate before upload is NOT_READY."""
+    from dc_sand_amd import BeamformerParameters, _lib
+    from dc_sand_amd.generator import SteeringCoefficientGenerator
+
+    bp = BeamformerParameters(NR_CHANNELS=8, NR_STATIONS=2, NR_BEAMS=2)
+    g = SteeringCoefficientGenerator(bp)
+    buf = gpu.mem_alloc(g.output_bytes(1, 1))
+    with pytest.raises(_lib.DcsError) as e:
+        g.generate(buf, buf.nbytes)
+    assert e.value.status == _lib.DCS_ERR_NOT_READY
+    g.upload_delays(rand_table(4))
+    with pytest.raises(_lib.DcsError) as e:
+        g.generate(buf, buf.nbytes, kernel=0, bitwidth=0)
+    assert e.value.status == _lib.DCS_ERR_UNSUPPORTED
+    with pytest.raises(_lib.DcsError) as e:
+        g.generate(buf, buf.nbytes, kernel=3)
+    assert e.value.status == _lib.DCS_ERR_UNSUPPORTED
+    with pytest.raises(_lib.DcsError) as e:
+        g.generate(buf, buf.nbytes - 1)
+    assert e.value.status == _lib.DCS_ERR_INVALID_ARGUMENT
+    g.close()
+
+
+def test_beam_shard_gather(gpu, oracle):
+    """set_delays_from_global: a context holding beams [off, off+B_loc) of a
+    global [A][B_total] device table produces that column slab of the global
+    tensor."""
+    from dc_sand_amd import BeamformerParameters
+    from dc_sand_amd.generator import SteeringCoefficientGenerator
+
+    A, B_total, C = 6, 40, 33
+    glob = rand_table(A * B_total, seed=9)
+    opg = oracle.params(C, A, B_total)
+    full = oracle.generate(opg, glob, 2, 2)
+    d_glob = gpu.mem_alloc(glob.nbytes)
+    gpu.memcpy_htod(d_glob, glob)
+    for off, bl in ((0, 10), (10, 10), (30, 10), (7, 33)):
+        bp = BeamformerParameters(NR_CHANNELS=C, NR_STATIONS=A, NR_BEAMS=bl)
+        g = SteeringCoefficientGenerator(bp)
+        g.set_delays_from_global(d_glob, B_total, off)
+        nbytes = g.output_bytes(1, 2)
+        buf = gpu.mem_alloc(nbytes)
+        g.generate(buf, nbytes, t0=2, nt=2)
+        out = np.empty((2, C, A, bl, 2), dtype=np.float32)
+        gpu.memcpy_dtoh(out, buf)
+        _check(oracle, out, np.ascontiguousarray(full[:, :, :, off:off + bl, :]))
+        g.close()
+
+
+def test_unit_test_harness_five_phases(gpu, oracle, capsys):
+    """The BeamformerCoeffTest mirror: run_test() -> result 1, three timed
+    phases, utilisation model; get_result() before run_test() is 0."""
+    from dc_sand_amd.beamformer_coeff_test import BeamformerCoeffTest, SteeringCoefficientBitWidth as BW, SteeringCoefficientKernel as K
+
+    def verifier(bp, delays, nt):
+        return oracle.generate(oracle.params_from(bp), np.asarray(delays), 0, nt)
+
+    for kern in (K.MULTIPLE_CHANNELS_AND_TIMESTAMPS, K.NAIVE):
+        t = BeamformerCoeffTest(1e-4, kern, BW.b32, verifier=verifier, verbose=False)
+        assert t.get_result() == 0
+        t.run_test()
+        assert t.get_result() == 1
+        assert t.max_ulp is not None and t.max_ulp <= 1
+        total = t.get_time()
+        assert total > 0 and t.m_fKernelElapsedTime_ms > 0
+        assert t.get_gpu_utilisation_per_single_time_unit() > 0
+    with pytest.raises(ValueError):
+        BeamformerCoeffTest(1e-4, K.NAIVE, BW.b16)
+
+
+def test_sincos_probe_fast_path_matches_host_sweep(gpu, oracle):
+    """The device evaluates dcs_sincos_fast to the same bits as the host build
+    swept exhaustively in test_numerics.py (sampled: 4M arguments)."""
+    import ctypes
+    from dc_sand_amd import _lib
+
+    rng = np.random.default_rng(1)
+    x = np.concatenate([
+        rng.uniform(-100, 100, 1 << 21).astype(np.float32),
+        rng.uniform(-32000, 32000, 1 << 20).astype(np.float32),
+        (np.arange(1, 1 << 20, dtype=np.float32) * np.float32(np.pi / 2)),  # near multiples of pi/2
+    ])
+    n = x.size
+    dx, ds, dc = gpu.mem_alloc(4 * n), gpu.mem_alloc(4 * n), gpu.mem_alloc(4 * n)
+    gpu.memcpy_htod(dx, x)
+    V = ctypes.c_void_p
+    for which, limit in ((0, 1), (2, 1)):
+        _lib.check(_lib.lib().dcs_probe_sincos(which, V(int(dx)), n, V(int(ds)), V(int(dc)), V(None)), "probe")
+        s = np.empty(n, np.float32)
+        c = np.empty(n, np.float32)
+        gpu.memcpy_dtoh(s, ds)
+        gpu.memcpy_dtoh(c, dc)
+        # the fast path is only used (and only proven) below DCS_SINCOS_FAST_LIMIT
+        sel = np.abs(x) < 32768.0 if which == 0 else np.ones(n, dtype=bool)
+        es = np.sin(x.astype(np.float64)).astype(np.float32)
+        ec = np.cos(x.astype(np.float64)).astype(np.float32)
+        assert oracle.max_ulp(s[sel], es[sel], limit)[1] == 0
+        assert oracle.max_ulp(c[sel], ec[sel], limit)[1] == 0
