@@ -1,0 +1,254 @@
+#!/usr/bin/env python3
+"""bench.py -- steering-coefficient throughput on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one batch: generate one time step of
+the 64 ant x 1024 beam x 32768 chan coefficient tensor (16 GiB, fp32 complex)
+per GPU from a delay table already resident in HBM.  With N > 1 (launched by
+``python -m torch.distributed.run``, one rank per GPU) the BEAM axis is sharded:
+the global table holds 1024*N beams, rank 0 broadcasts it over RCCL every step
+(prefetched on a side stream, double-buffered), each rank gathers its 1024-beam
+slice and generates its own column slab -- no other collective (weak scaling).
+
+Rank 0 prints ONE JSON line.  ``roofline`` prices the dominant kernel against
+the 8 TB/s HBM peak with its ALGORITHMIC bytes (8 B per coefficient written);
+``cpu_baseline`` times the CPU oracle (the restated reference verifier, one
+thread like the reference) on a bounded channel slab of the same workload.
+The oracle is used here only as the baseline being timed and as a spot check --
+never inside the timed GPU region.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s (spec)
+ANT, BEAMS_PER_GPU, CHAN = 64, 1024, 32768
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--ant", type=int, default=ANT)
+    ap.add_argument("--beams-per-gpu", type=int, default=BEAMS_PER_GPU)
+    ap.add_argument("--chan", type=int, default=CHAN)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline sample time")
+    return ap.parse_args()
+
+
+def cpu_baseline(bp, table, seconds: float) -> dict:
+    """Time the CPU oracle (restated reference verifier loop, serial like the
+    reference) on channels [0, nc) of the same workload, t = 1."""
+    from oracle import bf_oracle as orc
+
+    op = orc.params_from(bp)
+    n_pairs = bp.n_pairs
+    s, _ = orc.generate_checksum(op, table, 1, 1, 0, 16, 1)  # calibrate
+    rate = 16 * n_pairs / max(s, 1e-9)
+    nc = int(max(16, min(bp.NR_CHANNELS, rate * seconds / n_pairs)))
+    s1, ck1 = orc.generate_checksum(op, table, 1, 1, 0, nc, 1)
+    out = {
+        "value": nc * n_pairs / s1 / 1e9,
+        "unit": "Gcoeff/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": f"channels [0,{nc}) of {bp.NR_STATIONS}ant x {bp.NR_BEAMS}beam x {bp.NR_CHANNELS}chan, t=1, "
+                  f"{nc * n_pairs / 1e6:.0f} Mcoeff in {s1:.2f} s, 1 thread (the reference verifier is serial)",
+    }
+    ncores = os.cpu_count() or 1
+    if ncores > 1:
+        nt_threads = min(ncores, 64)
+        nc_mt = int(min(bp.NR_CHANNELS, max(nt_threads, nc * min(nt_threads, 8) // 3)))
+        s2, _ = orc.generate_checksum(op, table, 1, 1, 0, nc_mt, nt_threads)
+        out["all_cores"] = {"value": nc_mt * n_pairs / s2 / 1e9, "cores": nt_threads,
+                            "sample": f"channels [0,{nc_mt}) in {s2:.2f} s"}
+    return out
+
+
+def pmc_traffic(bytes_algo: int):
+    """HBM write bytes per launch from the committed rocprofv3 --pmc pass of this
+    same workload (profiles/pmc_write_size.json), or None."""
+    f = ROOT / "profiles" / "pmc_write_size.json"
+    try:
+        d = json.loads(f.read_text())
+        if int(d.get("algorithmic_bytes_per_launch", -1)) == int(bytes_algo):
+            return float(d["hbm_write_bytes_per_launch"])
+    except Exception:
+        pass
+    return None
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    N = max(world, 1)
+
+    import torch
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if N > 1:
+        import torch.distributed as dist  # noqa: F811
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    from dc_sand_amd import BeamformerParameters, device
+    from dc_sand_amd.generator import SteeringCoefficientGenerator, simulate_input
+    from dc_sand_amd.parameters import delay_vals_dtype
+
+    device.set_device(local_rank)
+    B_total = args.beams_per_gpu * N
+    bp_global = BeamformerParameters(NR_CHANNELS=args.chan, NR_STATIONS=args.ant, NR_BEAMS=B_total)
+    bp = bp_global.with_beams(args.beams_per_gpu)
+    beam_off = rank * args.beams_per_gpu
+    gen = SteeringCoefficientGenerator(bp)
+    out_bytes = gen.output_bytes(1, 1)
+    out = torch.empty(out_bytes, dtype=torch.uint8, device="cuda")
+    main_stream = torch.cuda.current_stream()
+    sh = main_stream.cuda_stream  # hipStream_t the kernels are launched on
+
+    # the global delay table: the reference's ramp recipe (simulate_input) over all
+    # A x B_total pairs, resident in HBM; two buffers so the next step's broadcast
+    # overlaps this step's generation
+    table_host = simulate_input(bp_global) if rank == 0 else np.zeros(bp_global.n_pairs, dtype=delay_vals_dtype)
+    tbl = [torch.from_numpy(table_host.view(np.uint8).copy()).cuda() for _ in range(2)]
+    comm_stream = torch.cuda.Stream() if N > 1 else None
+    ready = [torch.cuda.Event() for _ in range(2)]
+    freed = [torch.cuda.Event() for _ in range(2)]
+
+    def prefetch(k: int):
+        """Broadcast step k's table into buffer k % 2 on the comm stream."""
+        if N == 1:
+            return
+        b = k % 2
+        with torch.cuda.stream(comm_stream):
+            comm_stream.wait_event(freed[b])
+            dist.broadcast(tbl[b], src=0)
+            ready[b].record(comm_stream)
+
+    def step(k: int):
+        b = k % 2
+        if N > 1:
+            main_stream.wait_event(ready[b])
+        gen.set_delays_from_global(tbl[b].data_ptr(), B_total, beam_off, stream=sh)
+        freed[b].record(main_stream)
+        if N > 1:
+            prefetch(k + 1)
+        gen.generate(out.data_ptr(), out_bytes, t0=1 + (k % 255), nt=1, stream=sh)
+
+    for b in range(2):
+        freed[b].record(main_stream)
+    prefetch(0)
+    for k in range(args.warmup):
+        step(k)
+    torch.cuda.synchronize()
+    if N > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+
+    e0, e1 = device.Event(), device.Event()
+    t_start = time.perf_counter()
+    e0.record(sh)
+    for k in range(args.warmup, args.warmup + args.steps):
+        step(k)
+    e1.record(sh)
+    torch.cuda.synchronize()
+    if N > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t_start
+    ev_ms = e1.elapsed_ms_since(e0)
+
+    if N > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    coeffs_per_gpu_step = bp.coeffs_per_time_step()
+    total_coeffs = coeffs_per_gpu_step * N * args.steps
+    value = total_coeffs / elapsed / 1e9
+
+    result = None
+    if rank == 0:
+        # dominant kernel: the tiled generator; its duration = the HIP-event span on
+        # its own stream over the timed region / launches (one launch per step; the
+        # 16-KiB-per-row slice gather is the only other kernel there)
+        kern_ms = ev_ms / args.steps
+        algo_bytes = 8 * coeffs_per_gpu_step
+        achieved = algo_bytes / (kern_ms * 1e-3) / 1e9
+        # spot check of the last generated step against the oracle (outside the timed region)
+        from oracle import bf_oracle as orc
+
+        k_last = args.warmup + args.steps - 1
+        t_last = 1 + (k_last % 255)
+        nchk = 4
+        host = np.empty((nchk, args.ant, args.beams_per_gpu, 2), dtype=np.float32)
+        device.memcpy_dtoh(host, out.data_ptr(), nbytes=host.nbytes)
+        exp = orc.generate(orc.params_from(bp), table_host[: bp_global.n_pairs].reshape(args.ant, B_total)[:, :args.beams_per_gpu].ravel(),
+                           t_last, 1, 0, nchk)
+        mx, n_over, _ = orc.max_ulp(host, exp, 1)
+        result = {
+            "metric": f"Gcoeff/s (complex weights) {args.ant}ant x {args.beams_per_gpu}beam x {args.chan}chan per GPU",
+            "value": value,
+            "unit": "Gcoeff/s",
+            "n_gpus": N,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{args.ant}ant x {B_total}beam x {args.chan}chan, 1 time step per step, "
+                            f"beam-sharded {args.beams_per_gpu} beams/GPU" + (", RCCL bcast of the delay table each step" if N > 1 else ""),
+                "coeffs_per_step": coeffs_per_gpu_step * N,
+                "output_bytes_per_gpu_step": out_bytes,
+                "kernel": "MULTIPLE_CHANNELS_AND_TIMESTAMPS (tiled form, library defaults)",
+                "parity_spot_check_max_ulp": int(mx),
+                "parity_spot_check_over_1ulp": int(n_over),
+            },
+            "roofline": {
+                "bound": "hbm",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBPS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBPS,
+                "traffic": pmc_traffic(algo_bytes),
+                "kernel_ms": kern_ms,
+                "algorithmic_bytes_per_launch": algo_bytes,
+            },
+        }
+        if N == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(bp, np.ascontiguousarray(table_host), args.cpu_seconds)
+        print(json.dumps(result), flush=True)
+
+    gen.close()
+    if N > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

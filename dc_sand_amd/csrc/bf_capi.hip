@@ -85,14 +85,13 @@ struct dcs_bf_context {
 struct dcs_bf_stream {
     dcs_bf_context *ctx;
     hipStream_t stream;
-    hipGraphExec_t exec[2];
-    hipGraph_t graph[2];
-    float *h_dt;   // pinned, one float
-    float *d_dt;   // device, one float
-    dcs_delay_vals *h_table; // pinned staging for table updates
-    int bitwidth;
-    uint32_t c0, nc;
-    void *d_out;
+    hipGraph_t graph;
+    hipGraphExec_t exec;
+    hipGraphNode_t node;
+    bf_kernel_launch launch;     // the node's kernel, geometry and arguments
+    dcs_delay_vals *h_table;     // pinned staging for table updates
+    hipEvent_t table_copied;     // h_table may be rewritten after this
+    bool table_pending;
 };
 
 extern "C" {
@@ -389,8 +388,8 @@ void pick_geometry(const dcs_bf_context *c, bool out16, uint32_t nc, uint32_t nt
     *cpb = c->tune.chan_per_block ? (uint32_t)c->tune.chan_per_block : (out16 ? 32u : 16u);
 }
 
-int launch_tiled(dcs_bf_context *c, bool out16, const float *dt_dev, float dt0, uint32_t nt, uint32_t c0,
-                 uint32_t nc, void *d_out, hipStream_t stream)
+int prepare_tiled(dcs_bf_context *c, bool out16, const float *dt_dev, float dt0, uint32_t nt, uint32_t c0,
+                  uint32_t nc, void *d_out, bf_kernel_launch *l)
 {
     bf_tiled_args a;
     std::memset(&a, 0, sizeof(a));
@@ -408,7 +407,17 @@ int launch_tiled(dcs_bf_context *c, bool out16, const float *dt_dev, float dt0, 
     bool ntstore;
     pick_geometry(c, out16, nc, nt, &tpb, &cpb, &ntstore);
     a.chan_per_block = cpb;
-    return (int)bf_launch_tiled(a, out16, tpb | (c->tune.nomath ? 0x100 : 0), ntstore, stream);
+    return (int)bf_prepare_tiled(a, out16, tpb | (c->tune.nomath ? 0x100 : 0), ntstore, l);
+}
+
+int launch_tiled(dcs_bf_context *c, bool out16, const float *dt_dev, float dt0, uint32_t nt, uint32_t c0,
+                 uint32_t nc, void *d_out, hipStream_t stream)
+{
+    bf_kernel_launch l;
+    int st = prepare_tiled(c, out16, dt_dev, dt0, nt, c0, nc, d_out, &l);
+    if (st != DCS_OK || l.func == nullptr) return st;
+    void *params[] = {&l.args};
+    return (int)hipLaunchKernel(l.func, l.grid, l.block, params, 0, stream);
 }
 
 // Row-streaming form: terms pre-pass, then short waves in address order.
@@ -570,6 +579,10 @@ int dcs_bf_gpu_utilisation(const dcs_bf_params *p, float kernel_ms, float out[2]
 }
 
 /* ---- streaming ---------------------------------------------------------- */
+// The graph holds ONE kernel node (the tiled generator for one time step of the
+// slab).  A tick rewrites the node's arguments in the instantiated graph --
+// fDeltaTime by value, and the delay-table buffer when a new table has landed --
+// and replays it: no host synchronisation, no memcpy node.
 int dcs_bf_stream_begin(dcs_bf_context *c, int bitwidth, uint32_t c0, uint32_t nc, void *d_out, size_t out_bytes,
                         void *stream, dcs_bf_stream **out)
 {
@@ -580,43 +593,31 @@ int dcs_bf_stream_begin(dcs_bf_context *c, int bitwidth, uint32_t c0, uint32_t n
     if ((uint64_t)c0 + nc > (uint64_t)c->p.nr_channels || nc == 0) return DCS_ERR_OUT_OF_RANGE;
     const bool out16 = bitwidth == DCS_BF_B16;
     if (out_bytes < (size_t)nc * c->n_pairs * (out16 ? 4 : 8)) return DCS_ERR_INVALID_ARGUMENT;
-    if (stream == nullptr) return DCS_ERR_INVALID_ARGUMENT; // the null stream cannot be captured
 
     dcs_bf_stream *s = new (std::nothrow) dcs_bf_stream();
     if (!s) return (int)hipErrorOutOfMemory;
-    std::memset(s, 0, sizeof(*s));
+    std::memset(static_cast<void *>(s), 0, sizeof(*s));
     s->ctx = c;
     s->stream = as_stream(stream);
-    s->bitwidth = bitwidth;
-    s->c0 = c0;
-    s->nc = nc;
-    s->d_out = d_out;
     int st = DCS_OK;
     do {
-        if ((st = (int)hipHostMalloc((void **)&s->h_dt, sizeof(float), hipHostMallocDefault)) != 0) break;
-        if ((st = (int)hipMalloc((void **)&s->d_dt, sizeof(float))) != 0) break;
+        if ((st = prepare_tiled(c, out16, nullptr, 0.0f, 1, c0, nc, d_out, &s->launch)) != 0) break;
+        if (s->launch.func == nullptr) { st = DCS_ERR_INVALID_ARGUMENT; break; }
         if ((st = (int)hipHostMalloc((void **)&s->h_table, (size_t)c->n_pairs * sizeof(dcs_delay_vals),
-                                     hipHostMallocDefault)) != 0)
-            break;
-        *s->h_dt = 0.0f;
-        // one graph per table buffer: {H2D dt scalar -> generate one time step}
-        const int saved_cur = c->cur;
-        for (int b = 0; b < 2 && st == 0; b++) {
-            c->cur = b;
-            if ((st = (int)hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal)) != 0) break;
-            st = (int)hipMemcpyAsync(s->d_dt, s->h_dt, sizeof(float), hipMemcpyHostToDevice, s->stream);
-            if (st == 0) st = launch_form(c, out16, s->d_dt, 0.0f, 1, c0, nc, d_out, s->stream);
-            hipGraph_t g = nullptr;
-            const int st_end = (int)hipStreamEndCapture(s->stream, &g);
-            if (st == 0) st = st_end;
-            if (st != 0) {
-                if (g) (void)hipGraphDestroy(g);
-                break;
-            }
-            s->graph[b] = g;
-            st = (int)hipGraphInstantiate(&s->exec[b], g, nullptr, nullptr, 0);
-        }
-        c->cur = saved_cur;
+                                     hipHostMallocDefault)) != 0) break;
+        if ((st = (int)hipEventCreateWithFlags(&s->table_copied, hipEventDisableTiming)) != 0) break;
+        if ((st = (int)hipGraphCreate(&s->graph, 0)) != 0) break;
+        void *params[] = {&s->launch.args};
+        hipKernelNodeParams np;
+        std::memset(&np, 0, sizeof(np));
+        np.func = const_cast<void *>(s->launch.func);
+        np.gridDim = s->launch.grid;
+        np.blockDim = s->launch.block;
+        np.sharedMemBytes = 0;
+        np.kernelParams = params;
+        np.extra = nullptr;
+        if ((st = (int)hipGraphAddKernelNode(&s->node, s->graph, nullptr, 0, &np)) != 0) break;
+        if ((st = (int)hipGraphInstantiate(&s->exec, s->graph, nullptr, nullptr, 0)) != 0) break;
     } while (0);
     if (st != 0) {
         dcs_bf_stream_end(s);
@@ -634,34 +635,37 @@ int dcs_bf_stream_tick(dcs_bf_stream *s, uint64_t t, const dcs_delay_vals *new_t
     int st = dcs_bf_delta_times(&c->p, t, 1, &dt);
     if (st != DCS_OK) return st;
     if (new_table) {
-        // The idle buffer is not read by any launch still queued for the
-        // current one; the copy is ordered on the same stream before the
-        // graph that reads it.  h_table is reused: wait for the previous copy.
-        DCS_TRY(hipStreamSynchronize(s->stream));
+        // stage through pinned memory into the IDLE table buffer; replays already
+        // queued keep reading the current one (their arguments are baked in)
+        if (s->table_pending) DCS_TRY(hipEventSynchronize(s->table_copied));
         std::memcpy(s->h_table, new_table, (size_t)c->n_pairs * sizeof(dcs_delay_vals));
         const int nxt = c->cur ^ 1;
         DCS_TRY(hipMemcpyAsync(c->d_table[nxt], s->h_table, (size_t)c->n_pairs * sizeof(dcs_delay_vals),
                                hipMemcpyHostToDevice, s->stream));
+        DCS_TRY(hipEventRecord(s->table_copied, s->stream));
+        s->table_pending = true;
         c->cur = nxt;
-    } else {
-        // *h_dt is read by the graph's memcpy node when it executes: the
-        // previous replay must have consumed it before it is overwritten.
-        DCS_TRY(hipStreamSynchronize(s->stream));
     }
-    *s->h_dt = dt;
-    return (int)hipGraphLaunch(s->exec[c->cur], s->stream);
+    s->launch.args.dt0 = dt;
+    s->launch.args.delays = c->d_table[c->cur];
+    void *params[] = {&s->launch.args};
+    hipKernelNodeParams np;
+    std::memset(&np, 0, sizeof(np));
+    np.func = const_cast<void *>(s->launch.func);
+    np.gridDim = s->launch.grid;
+    np.blockDim = s->launch.block;
+    np.kernelParams = params;
+    DCS_TRY(hipGraphExecKernelNodeSetParams(s->exec, s->node, &np));
+    return (int)hipGraphLaunch(s->exec, s->stream);
 }
 
 int dcs_bf_stream_end(dcs_bf_stream *s)
 {
     if (!s) return DCS_OK;
-    if (s->stream) (void)hipStreamSynchronize(s->stream);
-    for (int b = 0; b < 2; b++) {
-        if (s->exec[b]) (void)hipGraphExecDestroy(s->exec[b]);
-        if (s->graph[b]) (void)hipGraphDestroy(s->graph[b]);
-    }
-    if (s->h_dt) (void)hipHostFree(s->h_dt);
-    if (s->d_dt) (void)hipFree(s->d_dt);
+    (void)hipStreamSynchronize(s->stream);
+    if (s->exec) (void)hipGraphExecDestroy(s->exec);
+    if (s->graph) (void)hipGraphDestroy(s->graph);
+    if (s->table_copied) (void)hipEventDestroy(s->table_copied);
     if (s->h_table) (void)hipHostFree(s->h_table);
     delete s;
     return DCS_OK;
@@ -686,6 +690,32 @@ int dcs_probe_store_pattern(void *d_out, uint32_t rows, uint32_t cols_kib, uint3
     if (!d_out) return DCS_ERR_INVALID_ARGUMENT;
     return (int)bf_launch_probe_pattern(d_out, rows, cols_kib, qb, rb, (uint32_t)order, (uint32_t)xcd_remap,
                                         nontemporal != 0, block_threads, as_stream(stream));
+}
+
+int dcs_probe_reduce(const void *d_in, size_t bytes, uint64_t *checksum, float *max_modulus_dev, void *stream)
+{
+    if ((!d_in && bytes) || !checksum || !max_modulus_dev || (bytes % 16u)) return DCS_ERR_INVALID_ARGUMENT;
+    const size_t n = 2 * (size_t)BF_PROBE_REDUCE_WAVES;
+    unsigned long long *d_part = nullptr;
+    unsigned long long *h_part = new (std::nothrow) unsigned long long[n];
+    if (!h_part) return (int)hipErrorOutOfMemory;
+    hipError_t e = hipMalloc((void **)&d_part, n * sizeof(unsigned long long));
+    if (e == hipSuccess) e = bf_launch_probe_reduce(d_in, bytes, d_part, as_stream(stream));
+    if (e == hipSuccess) e = hipMemcpyAsync(h_part, d_part, n * sizeof(unsigned long long), hipMemcpyDeviceToHost, as_stream(stream));
+    if (e == hipSuccess) e = hipStreamSynchronize(as_stream(stream));
+    if (d_part) (void)hipFree(d_part);
+    if (e == hipSuccess) {
+        uint64_t sum = 0;
+        uint32_t devbits = 0;
+        for (size_t w = 0; w < n / 2; w++) {
+            sum += h_part[2 * w];
+            if ((uint32_t)h_part[2 * w + 1] > devbits) devbits = (uint32_t)h_part[2 * w + 1];
+        }
+        *checksum = sum;
+        std::memcpy(max_modulus_dev, &devbits, sizeof(float));
+    }
+    delete[] h_part;
+    return (int)e;
 }
 
 } // extern "C"

@@ -24,6 +24,16 @@ struct bf_tiled_args {
     dcs_bf_consts k;
 };
 
+// A resolved launch (kernel instantiation, geometry, final arguments): what
+// bf_launch_tiled enqueues, and what a hipGraph kernel node is built from.
+struct bf_kernel_launch {
+    const void *func; // nullptr: nothing to launch (empty shape)
+    dim3 grid, block;
+    bf_tiled_args args;
+};
+hipError_t bf_prepare_tiled(const bf_tiled_args &a, bool out16, int tiles_per_block, bool nontemporal,
+                            bf_kernel_launch *out);
+
 // tiles_per_block in {1,2,4}; out16: packed half2 output; nontemporal: nt stores.
 hipError_t bf_launch_tiled(const bf_tiled_args &a, bool out16, int tiles_per_block,
                            bool nontemporal, hipStream_t stream);
@@ -76,5 +86,7 @@ hipError_t bf_launch_probe_fill(void *out, size_t bytes, bool nontemporal, hipSt
 hipError_t bf_launch_probe_pattern(void *out, uint32_t rows, uint32_t cols, uint32_t QB, uint32_t RB,
                                    uint32_t order, uint32_t xcd, bool nontemporal, uint32_t block_threads,
                                    hipStream_t stream);
+#define BF_PROBE_REDUCE_WAVES 8192
+hipError_t bf_launch_probe_reduce(const void *in, size_t bytes, unsigned long long *d_part, hipStream_t stream);
 
 #endif

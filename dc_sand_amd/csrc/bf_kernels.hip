@@ -458,48 +458,75 @@ __global__ void __launch_bounds__(1024) bf_probe_pattern_kernel(uintx4 *out, uin
     }
 }
 
-template <bool OUT16, int TPB, bool NT, bool ALIGNED>
-hipError_t launch_tiled_nm(const bf_tiled_args &a, bool nomath, dim3 grid, hipStream_t stream)
+// Full-tensor property probe: per-wave partials of an order-independent checksum
+// (sum of the 32-bit words, mod 2^64) and of max | |z|^2 - 1 | over fp32 (re, im)
+// pairs; the host adds the partials.  part[2*w] = checksum, part[2*w+1] = float bits.
+__global__ void __launch_bounds__(kBlock) bf_probe_reduce_kernel(const uintx4 *in, size_t n16,
+                                                                 unsigned long long *part)
 {
-    if (nomath)
-        hipLaunchKernelGGL((bf_tiled_kernel<OUT16, TPB, NT, ALIGNED, true>), grid, dim3(kBlock), 0, stream, a);
-    else
-        hipLaunchKernelGGL((bf_tiled_kernel<OUT16, TPB, NT, ALIGNED, false>), grid, dim3(kBlock), 0, stream, a);
-    return hipGetLastError();
+    unsigned long long sum = 0;
+    float dev = 0.0f;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n16; i += (size_t)gridDim.x * kBlock) {
+        const uintx4 u = in[i];
+        sum += (unsigned long long)u.x;
+        sum += (unsigned long long)u.y;
+        sum += (unsigned long long)u.z;
+        sum += (unsigned long long)u.w;
+        const float re0 = dcs_bits_f32(u.x), im0 = dcs_bits_f32(u.y), re1 = dcs_bits_f32(u.z), im1 = dcs_bits_f32(u.w);
+        const float m0 = dcs_fmaf(re0, re0, im0 * im0) - 1.0f, m1 = dcs_fmaf(re1, re1, im1 * im1) - 1.0f;
+        dev = fmaxf(dev, fmaxf(fabsf(m0), fabsf(m1)));
+        if (m0 != m0 || m1 != m1) dev = INFINITY;
+    }
+    uint32_t lo = (uint32_t)sum, hi = (uint32_t)(sum >> 32);
+    for (int o = 32; o > 0; o >>= 1) {
+        const uint32_t olo = (uint32_t)__shfl_down((int)lo, o), ohi = (uint32_t)__shfl_down((int)hi, o);
+        const unsigned long long t = (((unsigned long long)hi << 32) | lo) + (((unsigned long long)ohi << 32) | olo);
+        lo = (uint32_t)t;
+        hi = (uint32_t)(t >> 32);
+        dev = fmaxf(dev, __shfl_down(dev, o));
+    }
+    if ((threadIdx.x & 63u) == 0u) {
+        const size_t w = (size_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+        part[2 * w] = ((unsigned long long)hi << 32) | lo;
+        part[2 * w + 1] = (unsigned long long)dcs_f32_bits(dev);
+    }
+}
+
+template <bool OUT16, int TPB, bool NT, bool ALIGNED>
+const void *tiled_fn_nm(bool nomath)
+{
+    return nomath ? reinterpret_cast<const void *>(&bf_tiled_kernel<OUT16, TPB, NT, ALIGNED, true>)
+                  : reinterpret_cast<const void *>(&bf_tiled_kernel<OUT16, TPB, NT, ALIGNED, false>);
 }
 
 template <bool OUT16, int TPB>
-hipError_t launch_tiled_t(const bf_tiled_args &a, bool nt, bool aligned, bool nomath, dim3 grid,
-                          hipStream_t stream)
+const void *tiled_fn_t(bool nt, bool aligned, bool nomath)
 {
-    if (nt)
-        return aligned ? launch_tiled_nm<OUT16, TPB, true, true>(a, nomath, grid, stream)
-                       : launch_tiled_nm<OUT16, TPB, true, false>(a, nomath, grid, stream);
-    return aligned ? launch_tiled_nm<OUT16, TPB, false, true>(a, nomath, grid, stream)
-                   : launch_tiled_nm<OUT16, TPB, false, false>(a, nomath, grid, stream);
+    if (nt) return aligned ? tiled_fn_nm<OUT16, TPB, true, true>(nomath) : tiled_fn_nm<OUT16, TPB, true, false>(nomath);
+    return aligned ? tiled_fn_nm<OUT16, TPB, false, true>(nomath) : tiled_fn_nm<OUT16, TPB, false, false>(nomath);
 }
 
 template <bool OUT16>
-hipError_t launch_tiled_o(const bf_tiled_args &a, int tpb, bool nt, bool aligned, bool nomath, dim3 grid,
-                          hipStream_t stream)
+const void *tiled_fn_o(int tpb, bool nt, bool aligned, bool nomath)
 {
     switch (tpb) {
-    case 1: return launch_tiled_t<OUT16, 1>(a, nt, aligned, nomath, grid, stream);
-    case 2: return launch_tiled_t<OUT16, 2>(a, nt, aligned, nomath, grid, stream);
-    case 4: return launch_tiled_t<OUT16, 4>(a, nt, aligned, nomath, grid, stream);
-    default: return hipErrorInvalidValue;
+    case 1: return tiled_fn_t<OUT16, 1>(nt, aligned, nomath);
+    case 2: return tiled_fn_t<OUT16, 2>(nt, aligned, nomath);
+    case 4: return tiled_fn_t<OUT16, 4>(nt, aligned, nomath);
+    default: return nullptr;
     }
 }
 
 } // namespace
 
-hipError_t bf_launch_tiled(const bf_tiled_args &a_in, bool out16, int tiles_per_block, bool nontemporal,
-                           hipStream_t stream)
+hipError_t bf_prepare_tiled(const bf_tiled_args &a_in, bool out16, int tiles_per_block, bool nontemporal,
+                            bf_kernel_launch *out)
 {
     bf_tiled_args a = a_in;
-    if (a.n_pairs == 0 || a.nc == 0 || a.nt == 0) return hipSuccess;
+    out->func = nullptr;
+    if (a.n_pairs == 0 || a.nc == 0 || a.nt == 0) return hipSuccess; // nothing to launch
     if (a.chan_per_block == 0) return hipErrorInvalidValue;
-    const bool nomath = (tiles_per_block & 0x100) != 0; // probe flag, see bf_capi.cpp
+    const bool nomath = (tiles_per_block & 0x100) != 0; // probe flag, see bf_capi.hip
     tiles_per_block &= 0xff;
     const uint32_t ppl = out16 ? 4u : 2u;
     const uint32_t pairs_per_block = 64u * ppl * (uint32_t)tiles_per_block;
@@ -509,9 +536,24 @@ hipError_t bf_launch_tiled(const bf_tiled_args &a_in, bool out16, int tiles_per_
     if (blocks == 0 || blocks > 0x7fffffffull) return hipErrorInvalidValue;
     if (a.dt_dev == nullptr && a.nt != 1) return hipErrorInvalidValue;
     const bool aligned = (a.n_pairs % ppl) == 0 && (reinterpret_cast<uintptr_t>(a.out) % 16u) == 0;
-    const dim3 grid((uint32_t)blocks);
-    return out16 ? launch_tiled_o<true>(a, tiles_per_block, nontemporal, aligned, nomath, grid, stream)
-                 : launch_tiled_o<false>(a, tiles_per_block, nontemporal, aligned, nomath, grid, stream);
+    const void *fn = out16 ? tiled_fn_o<true>(tiles_per_block, nontemporal, aligned, nomath)
+                           : tiled_fn_o<false>(tiles_per_block, nontemporal, aligned, nomath);
+    if (!fn) return hipErrorInvalidValue;
+    out->func = fn;
+    out->grid = dim3((uint32_t)blocks);
+    out->block = dim3(kBlock);
+    out->args = a;
+    return hipSuccess;
+}
+
+hipError_t bf_launch_tiled(const bf_tiled_args &a, bool out16, int tiles_per_block, bool nontemporal,
+                           hipStream_t stream)
+{
+    bf_kernel_launch l;
+    hipError_t e = bf_prepare_tiled(a, out16, tiles_per_block, nontemporal, &l);
+    if (e != hipSuccess || l.func == nullptr) return e;
+    void *params[] = {&l.args};
+    return hipLaunchKernel(l.func, l.grid, l.block, params, 0, stream);
 }
 
 hipError_t bf_launch_naive(const bf_naive_args &a, hipStream_t stream)
@@ -645,4 +687,13 @@ hipError_t bf_launch_rows(const bf_rows_args &a_in, bool out16, int waves_per_bl
     const dim3 grid((uint32_t)blocks);
     return out16 ? launch_rows_o<true>(a, waves_per_block, rows_per_wave, nontemporal, aligned, nomath, grid, stream)
                  : launch_rows_o<false>(a, waves_per_block, rows_per_wave, nontemporal, aligned, nomath, grid, stream);
+}
+
+hipError_t bf_launch_probe_reduce(const void *in, size_t bytes, unsigned long long *d_part, hipStream_t stream)
+{
+    // d_part: 2 * BF_PROBE_REDUCE_WAVES entries
+    const size_t n16 = bytes / 16;
+    hipLaunchKernelGGL(bf_probe_reduce_kernel, dim3(BF_PROBE_REDUCE_WAVES / (kBlock / 64)), dim3(kBlock), 0, stream,
+                       reinterpret_cast<const uintx4 *>(in), n16, d_part);
+    return hipGetLastError();
 }

@@ -188,10 +188,12 @@ int dcs_bf_set_tuning(dcs_bf_context *ctx, const struct dcs_bf_tuning *t);
 int dcs_bf_gpu_utilisation(const struct dcs_bf_params *p, float kernel_ms, float out[2]);
 
 /* ---- streaming (BASELINE config 5) -------------------------------------- */
-/* Captures {dt upload -> generate one time step} into a hipGraph per delay-table
- * buffer.  Each tick replays it for time index t; a non-NULL new_table is
- * uploaded into the idle table buffer first and becomes current.  The slab
- * [c0, c0+nc) x all (antenna, beam) of one time step is rewritten in place. */
+/* A hipGraph with one kernel node (generate one time step of the channel slab
+ * [c0, c0+nc), all (antenna, beam), in place in d_out).  Each tick rewrites the
+ * node's arguments in the instantiated graph (fDeltaTime of time index t; the
+ * delay-table buffer) and replays it on `stream` -- no host synchronisation.  A
+ * non-NULL new_table is staged into the idle table buffer first and used from
+ * this tick on (time-varying delay polynomials, double-buffered). */
 typedef struct dcs_bf_stream dcs_bf_stream;
 int dcs_bf_stream_begin(dcs_bf_context *ctx, int bitwidth, uint32_t c0, uint32_t nc, void *d_out,
                         size_t out_bytes, void *stream, dcs_bf_stream **s);
@@ -210,6 +212,11 @@ int dcs_probe_fill(void *d_out, size_t bytes, int nontemporal, void *stream);
  * the HBM system sustains; see DESIGN.md "write patterns"). */
 int dcs_probe_store_pattern(void *d_out, uint32_t rows, uint32_t cols_kib, uint32_t qb, uint32_t rb, int order,
                             int xcd_remap, int nontemporal, uint32_t block_threads, void *stream);
+
+/* Whole-tensor properties of an fp32 coefficient tensor resident on the device:
+ * checksum = sum of its 32-bit words mod 2^64 (order independent), and
+ * max | re^2 + im^2 - 1 | (inf if any NaN).  Synchronises `stream`. */
+int dcs_probe_reduce(const void *d_in, size_t bytes, uint64_t *checksum, float *max_modulus_dev, void *stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,118 @@
+"""The C-ABI library: it loads, exports every symbol include/dcs_beamformer.h
+declares, and its host-only entry points agree with the oracle.  No GPU needed
+(no compute call is made)."""
+import ctypes
+import re
+from ctypes import byref
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _declared_functions():
+    text = (ROOT / "include" / "dcs_beamformer.h").read_text()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = re.findall(r"\b(dcs_[a-z0-9_]+)\s*\(", text)
+    return sorted(set(names))
+
+
+def test_header_symbols_are_exported_and_bound(dcs_lib):
+    from dc_sand_amd import _lib
+
+    declared = _declared_functions()
+    assert len(declared) >= 40
+    bound = {name for name, _, _ in _lib.SIGNATURES}
+    for name in declared:
+        assert hasattr(dcs_lib, name), f"{name} declared in the header but not exported"
+        assert name in bound, f"{name} has no ctypes signature in dc_sand_amd/_lib.py"
+    assert bound <= set(declared)
+    assert dcs_lib.dcs_abi_version() == 1
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from dc_sand_amd import _lib
+
+    monkeypatch.setattr(_lib, "_LIB", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", tmp_path / "nope.so")
+    with pytest.raises(ImportError, match="no CPU fallback"):
+        _lib.lib()
+
+
+def test_no_oracle_import_in_product():
+    """The product path never touches oracle/ (or the host numerics lab)."""
+    for f in (ROOT / "dc_sand_amd").rglob("*"):
+        if f.suffix in (".py", ".hip", ".h", ".cpp"):
+            txt = f.read_text()
+            assert "oracle" not in txt.replace("the oracle", "").replace("oracle's", "").replace("(oracle", "") or "import oracle" not in txt
+            assert "from oracle" not in txt and "import oracle" not in txt and "bf_oracle" not in txt
+            assert "numerics_lab" not in txt
+
+
+def test_default_params_match_reference_header(dcs_lib):
+    from dc_sand_amd.parameters import BeamformerParameters, CParams
+
+    cp = CParams()
+    assert dcs_lib.dcs_bf_default_params(byref(cp)) == 0
+    ref = BeamformerParameters()  # BeamformerParameters.h:7-17
+    assert (cp.nr_channels, cp.nr_stations, cp.nr_beams, cp.nr_samples_per_channel) == (64, 64, 16, 256)
+    assert cp.sampling_period == np.float32(1e-7) and cp.fft_size == 8192
+    assert cp.adc_sample_rate == 1712e6 and cp.accumulations_before_new_coeffs == 256
+    assert ref.to_c().sampling_period == cp.sampling_period
+
+
+def test_delta_times_and_simulate_input_equal_oracle(dcs_lib, oracle):
+    """The product's own host arithmetic (used for every launch) equals the
+    oracle's restatement of BeamformerCoefficientTest.cu:299,12-18,185-196."""
+    from dc_sand_amd import BeamformerParameters
+    from dc_sand_amd.generator import delta_times, simulate_input
+
+    for bp in (BeamformerParameters(), BeamformerParameters(NR_CHANNELS=1024, NR_STATIONS=4, NR_BEAMS=2),
+               BeamformerParameters(NR_CHANNELS=77, NR_STATIONS=5, NR_BEAMS=3, FFT_SIZE=4096, SAMPLING_PERIOD=2.5e-7)):
+        op = oracle.params_from(bp)
+        dts = delta_times(bp, 0, 1024)
+        exp = np.array([oracle.delta_time(op, t) for t in range(1024)], dtype=np.float32)
+        assert np.array_equal(dts.view(np.uint32), exp.view(np.uint32))
+        assert np.array_equal(simulate_input(bp).view(np.uint32), oracle.simulate_input(op).view(np.uint32))
+    big = delta_times(BeamformerParameters(), 10 ** 6, 4)
+    exp = np.array([oracle.delta_time(oracle.params(), 10 ** 6 + i) for i in range(4)], dtype=np.float32)
+    assert np.array_equal(big, exp)
+
+
+def test_output_bytes_and_utilisation(dcs_lib):
+    from dc_sand_amd import BeamformerParameters
+    from dc_sand_amd.generator import gpu_utilisation, output_bytes
+
+    bp = BeamformerParameters()
+    assert output_bytes(bp, 1, 256) == 256 * 64 * 64 * 16 * 2 * 4  # BeamformerCoefficientTest.cu:37
+    assert output_bytes(bp, 0, 256) == 256 * 64 * 64 * 16 * 2 * 2  # :34
+    big = BeamformerParameters(NR_CHANNELS=32768, NR_STATIONS=64, NR_BEAMS=1024)
+    assert output_bytes(big, 1, 1) == 16 * 2 ** 30
+    # BeamformerCoefficientTest.cu:426-430,447-448
+    single, multiple = gpu_utilisation(bp, 10.0)
+    rate = np.float32(1712e6) / np.float32(8192)
+    exp = np.float32((10.0 / 1000.0) / (256 * (np.float32(1) / rate))) * 4
+    assert abs(single - exp) <= 1e-6 * exp
+    assert abs(multiple - exp / 256) <= 1e-6 * exp
+
+
+def test_invalid_arguments_are_status_codes(dcs_lib):
+    from dc_sand_amd import _lib
+    from dc_sand_amd.parameters import BeamformerParameters
+
+    n = ctypes.c_size_t()
+    bad = BeamformerParameters(NR_CHANNELS=0).to_c()
+    assert dcs_lib.dcs_bf_output_bytes(byref(bad), 1, 1, byref(n)) == _lib.DCS_ERR_INVALID_ARGUMENT
+    good = BeamformerParameters().to_c()
+    assert dcs_lib.dcs_bf_output_bytes(byref(good), 7, 1, byref(n)) == _lib.DCS_ERR_INVALID_ARGUMENT
+    assert dcs_lib.dcs_bf_output_bytes(None, 1, 1, byref(n)) == _lib.DCS_ERR_INVALID_ARGUMENT
+    assert b"invalid argument" in dcs_lib.dcs_error_string(_lib.DCS_ERR_INVALID_ARGUMENT)
+    assert b"16 bit" in dcs_lib.dcs_error_string(_lib.DCS_ERR_UNSUPPORTED) or b"mode" in dcs_lib.dcs_error_string(_lib.DCS_ERR_UNSUPPORTED)
+    cnt = ctypes.c_int(-1)
+    assert dcs_lib.dcs_device_count(byref(cnt)) == 0 and cnt.value >= 0
+    if cnt.value == 0:  # no GPU here: creating a context is refused, not emulated
+        h = ctypes.c_void_p()
+        assert dcs_lib.dcs_bf_create(byref(good), byref(h)) == _lib.DCS_ERR_NO_DEVICE
+        assert not h.value

@@ -1,0 +1,102 @@
+"""Exhaustive CPU sweeps of the DEVICE arithmetic (dc_sand_amd/csrc/bf_math.h
+compiled for the host by tests/numerics): the exact fp32 operation sequences the
+gfx950 kernels execute -- an fp32 fma / mul / add gives the same bits on x86-64
+and on gfx950 -- checked against the oracle's definition for EVERY fp32 argument
+of the fast path's range.  tests/test_gpu_parity.py confirms on the GPU that the
+device reproduces these host bits.  No GPU needed.
+"""
+import ctypes
+import struct
+import subprocess
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+LAB_DIR = Path(__file__).resolve().parent / "numerics"
+
+
+def _bits(f: float) -> int:
+    return struct.unpack("<I", struct.pack("<f", f))[0]
+
+
+@pytest.fixture(scope="module")
+def lab():
+    res = subprocess.run(["make", "-C", str(LAB_DIR)], capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr
+    L = ctypes.CDLL(str(LAB_DIR / "libnumerics_lab.so"))
+    L.lab_sincos_sweep.argtypes = [ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int, ctypes.POINTER(ctypes.c_uint64)]
+    L.lab_div_sweep.argtypes = [ctypes.c_float, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int, ctypes.POINTER(ctypes.c_uint64)]
+    L.lab_sincos.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p]
+    L.lab_generate_fast.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int32, ctypes.c_float, ctypes.c_float,
+                                    ctypes.c_size_t, ctypes.c_size_t, ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64)]
+    return L
+
+
+def test_sincos_every_fp32_below_fast_limit(lab):
+    """Every positive fp32 in [2^-40, 32768): sin and cos within 1 ULP of
+    (float)sin((double)x) / (float)cos((double)x) -- 4.6e8 arguments.  (Below
+    2^-40 the reduction is the identity and sin x = x, cos x = 1 exactly.)"""
+    res = (ctypes.c_uint64 * 6)()
+    lab.lab_sincos_sweep(_bits(2.0 ** -40), _bits(32768.0), 8, res)
+    assert res[2] == 0 and res[3] == 0, f"over 1 ULP: sin {res[2]}, cos {res[3]}"
+    assert res[0] <= 1 and res[1] <= 1
+
+
+def test_sincos_symmetry_and_tiny_arguments(lab, oracle):
+    rng = np.random.default_rng(5)
+    x = np.concatenate([
+        -rng.uniform(0, 32000, 1 << 20).astype(np.float32),
+        rng.uniform(-100, 100, 1 << 20).astype(np.float32),
+        np.array([0.0, -0.0, 1e-45, -1e-45, 1e-38, 1e-30, 2.0 ** -41, np.pi / 2, np.pi, 3 * np.pi / 2, 2 * np.pi], dtype=np.float32),
+        (np.arange(1, 20000, dtype=np.float32) * np.float32(np.pi / 2)),
+    ])
+    s = np.empty_like(x)
+    c = np.empty_like(x)
+    lab.lab_sincos(x.ctypes.data, x.size, s.ctypes.data, c.ctypes.data)
+    es = np.sin(x.astype(np.float64)).astype(np.float32)
+    ec = np.cos(x.astype(np.float64)).astype(np.float32)
+    assert oracle.max_ulp(s, es, 1)[1] == 0
+    assert oracle.max_ulp(c, ec, 1)[1] == 0
+    # odd / even symmetry, bit for bit (the sign of a zero result aside: sin(-0)
+    # comes out +0, which the ULP metric equates with the oracle's -0)
+    s2 = np.empty_like(x)
+    c2 = np.empty_like(x)
+    xm = -x
+    lab.lab_sincos(xm.ctypes.data, x.size, s2.ctypes.data, c2.ctypes.data)
+    nz = x != 0
+    assert np.array_equal((-s2[nz]).view(np.uint32), s[nz].view(np.uint32))
+    assert np.array_equal(c2.view(np.uint32), c.view(np.uint32))
+
+
+@pytest.mark.parametrize("C", [1, 3, 64, 1000, 1024, 4096, 12345, 32768, 1 << 24])
+def test_divide_by_constant_is_correctly_rounded(lab, C):
+    """dcs_div_const(x, D) == x / D bit for bit for EVERY fp32 x in
+    [2^-60, 2^90] (1.26e9 values per D), D = SAMPLING_PERIOD * C."""
+    D = np.float32(1e-7) * np.float32(C)
+    res = (ctypes.c_uint64 * 4)()
+    lab.lab_div_sweep(D, _bits(2.0 ** -60), _bits(2.0 ** 90), 8, res)
+    assert res[0] == 0, f"{res[0]} mismatches, max {res[1]} ULP, first x bits {res[2]:#x}"
+    # negative arguments
+    lab.lab_div_sweep(D, _bits(-(2.0 ** -10)), _bits(-(2.0 ** 10)), 8, res)
+    assert res[0] == 0
+
+
+@pytest.mark.parametrize("C,A,B,seeded", [(1024, 4, 2, False), (64, 64, 16, False), (4096, 16, 16, True), (32768, 2, 64, True)])
+def test_emulated_fast_path_vs_oracle(lab, oracle, C, A, B, seeded):
+    """The whole device fast path (pair terms -> rotation -> sincos) on the host,
+    against the oracle: <= 1 ULP, at the time steps where the reference's dt
+    derivations disagree."""
+    from conftest import rand_table
+
+    p = oracle.params(C, A, B)
+    d = rand_table(A * B) if seeded else oracle.simulate_input(p)
+    c0, nc = (0, C) if C <= 4096 else (C - 3000, 3000)
+    for t in (0, 1, 5, 7, 9, 18, 255):
+        dt = oracle.delta_time(p, t)
+        exp = oracle.generate(p, d, t, 1, c0, nc)
+        got = np.empty_like(exp)
+        slow = ctypes.c_uint64()
+        lab.lab_generate_fast(d.ctypes.data, A * B, C, np.float32(1e-7), dt, c0, nc, got.ctypes.data, ctypes.byref(slow))
+        mx, n_over, first = oracle.max_ulp(got, exp, 1)
+        assert n_over == 0 and slow.value == 0, (t, mx, n_over, first)
