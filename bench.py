@@ -40,12 +40,16 @@ def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--ant", type=int, default=ANT)
     ap.add_argument("--beams-per-gpu", type=int, default=BEAMS_PER_GPU)
     ap.add_argument("--chan", type=int, default=CHAN)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline sample time")
+    # rehearsal of the N > 1 control flow on a box with fewer GPUs than ranks (never a result):
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="nccl = RCCL over xGMI (the product path)")
+    ap.add_argument("--shared-device", action="store_true", help="rehearsal: every rank uses GPU 0")
+    ap.add_argument("--check-all-ranks", action="store_true", help="every rank spot-checks its slab against the oracle")
     return ap.parse_args()
 
 
@@ -79,13 +83,13 @@ def cpu_baseline(bp, table, seconds: float) -> dict:
 
 
 def pmc_traffic(bytes_algo: int):
-    """HBM write bytes per launch from the committed rocprofv3 --pmc pass of this
+    """HBM bytes (write + corrected read) per launch from the committed rocprofv3 --pmc passes of this
     same workload (profiles/pmc_write_size.json), or None."""
     f = ROOT / "profiles" / "pmc_write_size.json"
     try:
         d = json.loads(f.read_text())
         if int(d.get("algorithmic_bytes_per_launch", -1)) == int(bytes_algo):
-            return float(d["hbm_write_bytes_per_launch"])
+            return float(d["hbm_bytes_per_launch"])
     except Exception:
         pass
     return None
@@ -104,13 +108,18 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+    if args.shared_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if N > 1:
         import torch.distributed as dist  # noqa: F811
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend="gloo")
 
     from dc_sand_amd import BeamformerParameters, device
     from dc_sand_amd.generator import SteeringCoefficientGenerator, simulate_input
@@ -188,6 +197,26 @@ def main():
     total_coeffs = coeffs_per_gpu_step * N * args.steps
     value = total_coeffs / elapsed / 1e9
 
+    def spot_check():
+        """First channels of the last generated step of THIS rank's slab vs the oracle
+        (outside the timed region)."""
+        from oracle import bf_oracle as orc
+
+        k_last = args.warmup + args.steps - 1
+        t_last = 1 + (k_last % 255)
+        nchk = 4
+        host = np.empty((nchk, args.ant, args.beams_per_gpu, 2), dtype=np.float32)
+        device.memcpy_dtoh(host, out.data_ptr(), nbytes=host.nbytes)
+        full = simulate_input(bp_global).reshape(args.ant, B_total)
+        local = np.ascontiguousarray(full[:, beam_off:beam_off + args.beams_per_gpu]).ravel()
+        exp = orc.generate(orc.params_from(bp), local, t_last, 1, 0, nchk)
+        mx, n_over, _ = orc.max_ulp(host, exp, 1)
+        return int(mx), int(n_over)
+
+    if args.check_all_ranks and rank != 0:
+        mx, n_over = spot_check()
+        assert n_over == 0, f"rank {rank}: {n_over} elements over 1 ULP (max {mx})"
+
     result = None
     if rank == 0:
         # dominant kernel: the tiled generator; its duration = the HIP-event span on
@@ -196,17 +225,7 @@ def main():
         kern_ms = ev_ms / args.steps
         algo_bytes = 8 * coeffs_per_gpu_step
         achieved = algo_bytes / (kern_ms * 1e-3) / 1e9
-        # spot check of the last generated step against the oracle (outside the timed region)
-        from oracle import bf_oracle as orc
-
-        k_last = args.warmup + args.steps - 1
-        t_last = 1 + (k_last % 255)
-        nchk = 4
-        host = np.empty((nchk, args.ant, args.beams_per_gpu, 2), dtype=np.float32)
-        device.memcpy_dtoh(host, out.data_ptr(), nbytes=host.nbytes)
-        exp = orc.generate(orc.params_from(bp), table_host[: bp_global.n_pairs].reshape(args.ant, B_total)[:, :args.beams_per_gpu].ravel(),
-                           t_last, 1, 0, nchk)
-        mx, n_over, _ = orc.max_ulp(host, exp, 1)
+        mx, n_over = spot_check()
         result = {
             "metric": f"Gcoeff/s (complex weights) {args.ant}ant x {args.beams_per_gpu}beam x {args.chan}chan per GPU",
             "value": value,
@@ -222,10 +241,11 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": f"{args.ant}ant x {B_total}beam x {args.chan}chan, 1 time step per step, "
-                            f"beam-sharded {args.beams_per_gpu} beams/GPU" + (", RCCL bcast of the delay table each step" if N > 1 else ""),
+                            f"beam-sharded {args.beams_per_gpu} beams/GPU" + (f", {args.backend} bcast of the delay table each step" if N > 1 else ""),
                 "coeffs_per_step": coeffs_per_gpu_step * N,
                 "output_bytes_per_gpu_step": out_bytes,
                 "kernel": "MULTIPLE_CHANNELS_AND_TIMESTAMPS (tiled form, library defaults)",
+                "collective": ("none" if N == 1 else ("RCCL broadcast" if args.backend == "nccl" else "gloo broadcast (REHEARSAL, not a result)")),
                 "parity_spot_check_max_ulp": int(mx),
                 "parity_spot_check_over_1ulp": int(n_over),
             },

@@ -88,5 +88,6 @@ hipError_t bf_launch_probe_pattern(void *out, uint32_t rows, uint32_t cols, uint
                                    hipStream_t stream);
 #define BF_PROBE_REDUCE_WAVES 8192
 hipError_t bf_launch_probe_reduce(const void *in, size_t bytes, unsigned long long *d_part, hipStream_t stream);
+hipError_t bf_warm_module();
 
 #endif
