@@ -10,7 +10,10 @@ from pathlib import Path
 
 from .parameters import CParams
 
-LIB_PATH = Path(__file__).resolve().parent / "csrc" / "libdcs_beamformer.so"
+import os
+
+# DCS_LIB_PATH: load another build of the SAME library (A/B of compiler flags in tools/); never a fallback.
+LIB_PATH = Path(os.environ.get("DCS_LIB_PATH") or (Path(__file__).resolve().parent / "csrc" / "libdcs_beamformer.so"))
 
 # status codes (include/dcs_beamformer.h)
 DCS_OK = 0

@@ -6,6 +6,7 @@ Flags that are part of the numerical contract (DESIGN.md "numerics"):
   -ffp-contract=off   no fused multiply-add except where bf_math.h writes one;
   (default)           -fhip-fp32-correctly-rounded-divide-sqrt stays on;
   (default)           fp32 denormals are kept (no -fgpu-flush-denormals-to-zero).
+Performance-only: -fno-slp-vectorize (scalar fp32 VALU ops instead of v_pk_*_f32).
 """
 from __future__ import annotations
 
@@ -37,6 +38,7 @@ def flags() -> list[str]:
         "-std=c++17",
         "-ffp-contract=off",
         "-fno-fast-math",
+        "-fno-slp-vectorize",  # v_pk_*_f32 packing costs 1.3 % (fp32) / 6 % (fp16) here: profiles/r01_geometry_sweep.md
         "-fPIC",
         "-Wall",
         "-Wextra",
