@@ -41,6 +41,9 @@ class SteeringCoefficientBitWidth(enum.IntEnum):
 
 
 Verifier = Callable[[BeamformerParameters, np.ndarray, int], np.ndarray]
+#: expected beams for the fused kernel: (params, delays[b*A+a], nt, antenna int8[c][nt/16][a][16][2]) -> float32
+BeamVerifier = Callable[[BeamformerParameters, np.ndarray, int, np.ndarray], np.ndarray]
+INTERNAL_TIME_SAMPLES = 16  # BeamformerParameters.h:51
 
 
 class BeamformerCoeffTest(UnitTest):
@@ -52,6 +55,7 @@ class BeamformerCoeffTest(UnitTest):
         params: Optional[BeamformerParameters] = None,
         verifier: Optional[Verifier] = None,
         verbose: bool = True,
+        beam_verifier: Optional[BeamVerifier] = None,
     ):
         require_device()
         super().__init__()
@@ -60,45 +64,66 @@ class BeamformerCoeffTest(UnitTest):
         self.m_eKernelOption = SteeringCoefficientKernel(eKernelOption)
         self.m_eBitWidth = SteeringCoefficientBitWidth(eBitWidth)
         self._verifier = verifier
+        self._beam_verifier = beam_verifier
         self._verbose = verbose
         self.max_ulp: Optional[int] = None
+        self.max_abs_diff: Optional[float] = None
         p = self.params
         K, BW = SteeringCoefficientKernel, SteeringCoefficientBitWidth
 
         # BeamformerCoefficientTest.cu:40-50 -- the reference prints and throws
         if self.m_eKernelOption in (K.NAIVE, K.COMBINED_COEFF_GEN_AND_BEAMFORMER_SINGLE_CHANNEL) and self.m_eBitWidth == BW.b16:
             raise ValueError("This kernel does not support 16 bit steering coefficients.")
-        if self.m_eKernelOption == K.COMBINED_COEFF_GEN_AND_BEAMFORMER_SINGLE_CHANNEL:
-            raise NotImplementedError(
-                "COMBINED_COEFF_GEN_AND_BEAMFORMER_SINGLE_CHANNEL is outside this build's hot path (SURVEY.md section 8 f1)"
-            )
+        self._combined = self.m_eKernelOption == K.COMBINED_COEFF_GEN_AND_BEAMFORMER_SINGLE_CHANNEL
+        # (the reference also requires NR_BEAMS == 16 and NR_STATIONS == 64 for the fused
+        #  kernel, BeamformerCoefficientTest.cu:46-50; this build accepts any shape)
+        if self._combined and p.NR_SAMPLES_PER_CHANNEL % INTERNAL_TIME_SAMPLES:
+            raise ValueError("NR_SAMPLES_PER_CHANNEL must be a multiple of 16 for the fused kernel")
 
         # BeamformerCoefficientTest.cu:24-38
         self.m_ulSizeDelayValues = p.n_pairs * delay_vals_dtype.itemsize
         self.m_ulSizeSteeringCoefficients = output_bytes(p, int(self.m_eBitWidth), p.NR_SAMPLES_PER_CHANNEL)
+        self.m_ulSizeInputAntennaData = p.NR_STATIONS * p.NR_CHANNELS * p.NR_SAMPLES_PER_CHANNEL * 2
+        self.m_ulSizeOutputBeamData = p.NR_BEAMS * p.NR_CHANNELS * p.NR_SAMPLES_PER_CHANNEL * 2 * 4
         if verbose:
             print(f"{self.m_ulSizeSteeringCoefficients / 1e6:g} MB Allocated for steering coefficients")
             print(f"{self.m_ulSizeDelayValues / 1e6:g} MB Allocated for delay values")
+            print(f"{self.m_ulSizeInputAntennaData / 1e6:g} MB Allocated for input antenna data")
+            print(f"{self.m_ulSizeOutputBeamData / 1e6:g} MB Allocated for output beam data")
 
         # BeamformerCoefficientTest.cu:73-87 -- pinned host + device buffers
         self.m_pHDelayValues = pagelocked_empty(p.n_pairs, delay_vals_dtype)
-        host_dtype = np.float16 if self.m_eBitWidth == BW.b16 else np.float32
-        self.m_pfHSteeringCoeffs = pagelocked_empty(self.m_ulSizeSteeringCoefficients // np.dtype(host_dtype).itemsize, host_dtype)
-        self.m_pfDSteeringCoeffs = mem_alloc(self.m_ulSizeSteeringCoefficients)
+        if not self._combined:
+            host_dtype = np.float16 if self.m_eBitWidth == BW.b16 else np.float32
+            self.m_pfHSteeringCoeffs = pagelocked_empty(self.m_ulSizeSteeringCoefficients // np.dtype(host_dtype).itemsize, host_dtype)
+            self.m_pfDSteeringCoeffs = mem_alloc(self.m_ulSizeSteeringCoefficients)
+        else:
+            self.m_pi8HInputAntennaData = pagelocked_empty(self.m_ulSizeInputAntennaData, np.int8)
+            self.m_pi8DInputAntennaData = mem_alloc(self.m_ulSizeInputAntennaData)
+            self.m_pfHOutputBeams = pagelocked_empty(self.m_ulSizeOutputBeamData // 4, np.float32)
+            self.m_pfDOutputBeams = mem_alloc(self.m_ulSizeOutputBeamData)
         self._gen = SteeringCoefficientGenerator(p)  # owns m_pDDelayValues
         self.m_fGpuUtilisation_SingleTimeUnit = 0.0
         self.m_fGpuUtilisation_MultipleTimeUnits = 0.0
 
-    # -- BeamformerCoefficientTest.cu:185-196 ---------------------------------
+    # -- BeamformerCoefficientTest.cu:185-205 ---------------------------------
     def simulate_input(self) -> None:
         self.m_pHDelayValues[:] = simulate_input(self.params)
+        if self._combined:  # :198-204: byte i = static_cast<int8_t>(i)
+            self.m_pi8HInputAntennaData[:] = (np.arange(self.m_ulSizeInputAntennaData, dtype=np.uint64) & 0xFF).astype(np.uint8).view(np.int8)
 
     # -- BeamformerCoefficientTest.cu:207-216 ---------------------------------
     def transfer_HtoD(self) -> None:
         self._gen.upload_delays(self.m_pHDelayValues)
+        if self._combined:
+            memcpy_htod(self.m_pi8DInputAntennaData, self.m_pi8HInputAntennaData)
 
     # -- BeamformerCoefficientTest.cu:218-264 ---------------------------------
     def run_kernel(self) -> None:
+        if self._combined:
+            self._gen.generate_and_beamform(self.m_pi8DInputAntennaData, self.m_ulSizeInputAntennaData, self.m_pfDOutputBeams,
+                                            self.m_ulSizeOutputBeamData, t0=0, nt=self.params.NR_SAMPLES_PER_CHANNEL)
+            return
         self._gen.generate(
             self.m_pfDSteeringCoeffs,
             self.m_ulSizeSteeringCoefficients,
@@ -110,10 +135,32 @@ class BeamformerCoeffTest(UnitTest):
 
     # -- BeamformerCoefficientTest.cu:266-276 ---------------------------------
     def transfer_DtoH(self) -> None:
-        memcpy_dtoh(self.m_pfHSteeringCoeffs, self.m_pfDSteeringCoeffs)
+        if self._combined:
+            memcpy_dtoh(self.m_pfHOutputBeams, self.m_pfDOutputBeams)
+        else:
+            memcpy_dtoh(self.m_pfHSteeringCoeffs, self.m_pfDSteeringCoeffs)
 
     # -- BeamformerCoefficientTest.cu:278-361 ---------------------------------
     def verify_output(self) -> None:
+        if self._combined:  # :363-414
+            if self._beam_verifier is None:
+                if self._verbose:
+                    print("No beam verifier supplied - result left at 0 (not run)")
+                return
+            p = self.params
+            ant = np.asarray(self.m_pi8HInputAntennaData).reshape(p.NR_CHANNELS, p.NR_SAMPLES_PER_CHANNEL // 16, p.NR_STATIONS, 16, 2)
+            expect = np.asarray(self._beam_verifier(p, self.m_pHDelayValues, p.NR_SAMPLES_PER_CHANNEL, ant), dtype=np.float32).ravel()
+            got = self.m_pfHOutputBeams
+            diff = np.abs(got - expect)
+            self.max_abs_diff = float(np.max(diff)) if diff.size else 0.0
+            bad = np.flatnonzero(~(diff <= self.m_fFloatingPointTolerance))
+            if bad.size:
+                i = int(bad[0])
+                print(f"Error Detected:\n\tIndex {i}: Simulated {expect[i]} Generated {got[i]}. Tolerance: {self.m_fFloatingPointTolerance}")
+                self.m_iResult = -1
+                return
+            self.m_iResult = 1
+            return
         if self._verifier is None:
             if self._verbose:
                 print("No verifier supplied - result left at 0 (not run)")
@@ -143,6 +190,11 @@ class BeamformerCoeffTest(UnitTest):
 
     # -- BeamformerCoefficientTest.cu:422-454 ---------------------------------
     def get_time(self) -> float:
+        if self._combined:  # :449-452
+            ratio = self.m_fKernelElapsedTime_ms / self.m_fHtoDElapsedTime_ms if self.m_fHtoDElapsedTime_ms > 0 else float("inf")
+            self.m_fGpuUtilisation_SingleTimeUnit = ratio
+            self.m_fGpuUtilisation_MultipleTimeUnits = ratio
+            return super().get_time()
         single, multiple = gpu_utilisation(self.params, self.m_fKernelElapsedTime_ms)
         self.m_fGpuUtilisation_SingleTimeUnit = single
         self.m_fGpuUtilisation_MultipleTimeUnits = multiple

@@ -300,6 +300,11 @@ int dcs_bf_create(const dcs_bf_params *p, dcs_bf_context **out)
         if ((st = (int)hipMalloc((void **)&c->d_terms, (size_t)c->terms_steps * c->pairs_pad * 8u)) != 0) break;
         if ((st = (int)hipMalloc((void **)&c->d_flags, (size_t)c->terms_steps * (c->pairs_pad / 64u) * 4u)) != 0) break;
         for (int i = 0; i < kDtSlots && st == 0; i++) st = (int)hipEventCreateWithFlags(&c->dt_ev[i], hipEventDisableTiming);
+        if (st != 0) break;
+        // first use of the pinned->device copy path costs ~0.25 ms once: pay it here,
+        // not inside the caller's first timed launch
+        c->h_dt[0] = 0.0f;
+        st = (int)hipMemcpy(c->d_dt, c->h_dt, sizeof(float), hipMemcpyHostToDevice);
     } while (0);
     if (st != 0) {
         dcs_bf_destroy(c);
@@ -560,6 +565,65 @@ int dcs_bf_generate(dcs_bf_context *c, int kernel, int bitwidth, uint64_t t0, ui
             st = launch_tiled(c, out16, nullptr, dt, 1, 0, C, dst, s);
         }
         if (st != DCS_OK) return st;
+    }
+    return DCS_OK;
+}
+
+int dcs_bf_generate_and_beamform(dcs_bf_context *c, uint64_t t0, uint32_t nt, const int8_t *d_antenna,
+                                 size_t antenna_bytes, float *d_beams, size_t beams_bytes, void *stream)
+{
+    if (!c || (nt && (!d_antenna || !d_beams))) return DCS_ERR_INVALID_ARGUMENT;
+    if ((t0 % 16u) || (nt % 16u)) return DCS_ERR_INVALID_ARGUMENT; // INTERNAL_TIME_SAMPLES, BeamformerParameters.h:51
+    if (!c->table_set) return DCS_ERR_NOT_READY;
+    const uint32_t A = (uint32_t)c->p.nr_stations, B = (uint32_t)c->p.nr_beams, C = (uint32_t)c->p.nr_channels;
+    if (A > 2048u) return DCS_ERR_UNSUPPORTED; // one [A][16][2] int8 block must fit the LDS staging buffer
+    // BeamformerCoefficientTest.cu:25-26 (sizes of the antenna and beam tensors)
+    if (antenna_bytes < (size_t)A * C * nt * 2u) return DCS_ERR_INVALID_ARGUMENT;
+    if (beams_bytes < (size_t)B * C * nt * 2u * sizeof(float)) return DCS_ERR_INVALID_ARGUMENT;
+    if ((reinterpret_cast<uintptr_t>(d_antenna) & 3u) || (reinterpret_cast<uintptr_t>(d_beams) & 7u))
+        return DCS_ERR_INVALID_ARGUMENT;
+    hipStream_t s = as_stream(stream);
+    uint32_t chunk = c->terms_steps & ~15u; // time steps per launch: what the terms table holds
+    if (chunk > kDtSlotFloats) chunk = kDtSlotFloats;
+    if (chunk == 0) return DCS_ERR_UNSUPPORTED;
+    for (uint32_t done = 0; done < nt;) {
+        const uint32_t n = (nt - done) < chunk ? (nt - done) : chunk;
+        const float *dt_dev = nullptr;
+        int st = stage_dt(c, t0 + done, n, s, &dt_dev);
+        if (st != DCS_OK) return st;
+        DCS_TRY(hipMemsetAsync(c->d_flags, 0, (size_t)n * sizeof(uint32_t), s));
+        bf_bform_terms_args ta;
+        std::memset(&ta, 0, sizeof(ta));
+        ta.delays = c->d_table[c->cur];
+        ta.terms = c->d_terms;
+        ta.flags = c->d_flags;
+        ta.dt_dev = dt_dev;
+        ta.n_pairs = c->n_pairs;
+        ta.A = A;
+        ta.B = B;
+        ta.nt = n;
+        ta.k = c->k;
+        DCS_TRY(bf_launch_bform_terms(ta, s));
+        bf_beamform_args a;
+        std::memset(&a, 0, sizeof(a));
+        a.terms = c->d_terms;
+        a.flags = c->d_flags;
+        a.ant = d_antenna;
+        a.beams = d_beams;
+        a.A = A;
+        a.B = B;
+        a.C = C;
+        a.nt16 = n / 16u;
+        a.tex0 = done / 16u;
+        a.nt16_total = nt / 16u;
+        // enough workgroups to fill the chip, but keep a few channels per workgroup
+        // so the staged terms lines are reused from L1
+        uint32_t cpb = 8;
+        while (cpb > 1 && (uint64_t)((B + 15u) / 16u) * ((C + cpb - 1) / cpb) * a.nt16 < 2048u) cpb >>= 1;
+        a.chan_per_block = cpb;
+        a.k = c->k;
+        DCS_TRY(bf_launch_beamform(a, s));
+        done += n;
     }
     return DCS_OK;
 }

@@ -64,6 +64,32 @@ struct bf_rows_args {
 hipError_t bf_launch_rows(const bf_rows_args &a, bool out16, int waves_per_block, int rows_per_wave,
                           bool nontemporal, bool xcd_remap, bool nomath, hipStream_t stream);
 
+// Fused coefficient generation + beamforming (table indexed [b*A + a]).
+struct bf_bform_terms_args {
+    const dcs_delay_vals *delays; // [B][A]
+    float *terms;                 // [nt][A][B][2]
+    uint32_t *flags;              // [nt], zeroed by the caller; |= 1 if any pair is slow at t
+    const float *dt_dev;          // [nt]
+    uint32_t n_pairs, A, B, nt;
+    dcs_bf_consts k;
+};
+hipError_t bf_launch_bform_terms(const bf_bform_terms_args &a, hipStream_t stream);
+
+struct bf_beamform_args {
+    const float *terms;    // [nt16*16][A][B][2] for this launch's time steps
+    const uint32_t *flags; // [nt16*16]
+    const int8_t *ant;     // [C][nt16_total][A][16][2]
+    float *beams;          // [C][nt16_total][B][16][2]
+    uint32_t A, B, C;
+    uint32_t nt16;         // 16-sample blocks in this launch
+    uint32_t tex0;         // first of them within the whole tensor
+    uint32_t nt16_total;
+    uint32_t chan_per_block;
+    uint32_t n_bgroups, n_cblocks; // filled by the launcher
+    dcs_bf_consts k;
+};
+hipError_t bf_launch_beamform(const bf_beamform_args &a, hipStream_t stream);
+
 // One coefficient per lane, one time step (reference kernel a1's shape).
 struct bf_naive_args {
     const dcs_delay_vals *delays;

@@ -355,6 +355,110 @@ __global__ void __launch_bounds__(kBlock) bf_terms_kernel(const bf_terms_args a)
 }
 
 // ---------------------------------------------------------------------------
+// Fused coefficient generation + beamforming (reference
+// calculate_beamweights_and_beamform_single_channel, BeamformerKernels.cu:192-367,
+// verified by BeamformerCoefficientTest.cu:363-414):
+//   beams[c][t/16][b][t%16] = sum over antennas a, IN ANTENNA ORDER, of
+//       ( cos(rot) * sample.re , sin(rot) * sample.im )        -- an element-wise
+// product, as the reference computes it (:315-316, verifier :391-392), with the
+// table indexed [b*A + a].  No coefficient is ever written to HBM: per output
+// 8 bytes leave the chip for 2*A sincos evaluations, so this kernel is bound by
+// the fp32 VALU rate, not by HBM.
+//
+// A lane owns one (time, beam) output and walks the antennas sequentially (the
+// verifier's summation order, separate multiply and add -- no fma), so the only
+// difference from the verifier is the <= 1 ULP of each coefficient.  The
+// channel-independent terms come from the table bf_bform_terms_kernel writes,
+// laid out [t][a][b] so that a wave's 16 beams x 4 times read four 128-byte
+// lines per antenna (L2-resident, reused by every channel); the int8 samples of
+// one (channel, 16 times) block are staged in LDS once per channel.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock) bf_bform_terms_kernel(const bf_bform_terms_args a)
+{
+    const uint32_t p = blockIdx.x * kBlock + threadIdx.x; // table index b*A + a
+    const uint32_t t = blockIdx.y;
+    bool slow = false;
+    if (p < a.n_pairs) {
+        const floatx4 raw = *reinterpret_cast<const floatx4 *>(&a.delays[p]);
+        dcs_delay_vals d;
+        d.fDelay_s = raw.x;
+        d.fDelayRate_sps = raw.y;
+        d.fPhase_rad = raw.z;
+        d.fPhaseRate_radps = raw.w;
+        float fRate, fPhase0;
+        dcs_pair_terms(d, a.dt_dev[t], a.k.dHalfChannels, a.k.dDenominator, &fRate, &fPhase0);
+        slow = !dcs_pair_is_fast(fRate, fPhase0, a.k.fRotBoundScale);
+        const uint32_t b = p / a.A, ant = p - b * a.A;
+        *reinterpret_cast<floatx2 *>(a.terms + 2u * ((uint64_t)t * a.n_pairs + (uint64_t)ant * a.B + b)) =
+            floatx2{fRate, fPhase0};
+    }
+    if (__builtin_amdgcn_ballot_w64(slow) != 0ull && (threadIdx.x & 63u) == 0u) atomicOr(&a.flags[t], 1u);
+}
+
+__global__ void __launch_bounds__(kBlock) bf_beamform_kernel(const bf_beamform_args a)
+{
+    extern __shared__ __attribute__((aligned(16))) int8_t s_ant[]; // [A][16][2]
+
+    const uint32_t bid = blockIdx.x;
+    const uint32_t bg = bid % a.n_bgroups;
+    const uint32_t rest = bid / a.n_bgroups;
+    const uint32_t cb = rest % a.n_cblocks;
+    const uint32_t tex = rest / a.n_cblocks; // 16-sample block within this launch
+
+    const uint32_t b_local = threadIdx.x & 15u, t_in = threadIdx.x >> 4;
+    const uint32_t b = bg * 16u + b_local;
+    const uint32_t t = tex * 16u + t_in; // time index within this launch's terms table
+    const bool live = b < a.B;
+
+    // any pair of these 16 time steps outside the fast path's proven range?
+    const int slow = __syncthreads_or((int)a.flags[tex * 16u + (threadIdx.x & 15u)]);
+
+    const float D = a.k.fDenominator, y = a.k.fRcpDenominator;
+    const float *tp = a.terms + 2u * ((uint64_t)t * a.A * a.B + (live ? b : 0u));
+    const uint32_t cbeg = cb * a.chan_per_block;
+    const uint32_t cend = min(cbeg + a.chan_per_block, a.C);
+    const uint32_t tex_g = a.tex0 + tex; // 16-sample block within the whole tensor
+    const uint32_t words = a.A * 8u;     // dwords of one [A][16][2] int8 block
+
+    for (uint32_t c = cbeg; c < cend; c++) {
+        __syncthreads(); // previous channel's readers are done
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(a.ant) + ((uint64_t)c * a.nt16_total + tex_g) * words;
+        for (uint32_t i = threadIdx.x; i < words; i += kBlock) reinterpret_cast<uint32_t *>(s_ant)[i] = src[i];
+        __syncthreads();
+
+        const float fChan = (float)c;
+        float acc_re = 0.0f, acc_im = 0.0f;
+        if (!slow) {
+#pragma unroll 4
+            for (uint32_t ant = 0; ant < a.A; ant++) {
+                const floatx2 kp = *reinterpret_cast<const floatx2 *>(tp + 2u * (uint64_t)ant * a.B);
+                float re, im;
+                coeff_fast(kp.x, kp.y, fChan, D, y, re, im);
+                const float sre = (float)s_ant[(ant * 16u + t_in) * 2u], sim = (float)s_ant[(ant * 16u + t_in) * 2u + 1u];
+                const float pr = re * sre, pi = im * sim; // product, then sum: two roundings each
+                acc_re = acc_re + pr;
+                acc_im = acc_im + pi;
+            }
+        } else {
+            for (uint32_t ant = 0; ant < a.A; ant++) {
+                const floatx2 kp = *reinterpret_cast<const floatx2 *>(tp + 2u * (uint64_t)ant * a.B);
+                float re, im;
+                coeff_slow(kp.x, kp.y, fChan, D, re, im);
+                const float sre = (float)s_ant[(ant * 16u + t_in) * 2u], sim = (float)s_ant[(ant * 16u + t_in) * 2u + 1u];
+                const float pr = re * sre, pi = im * sim;
+                acc_re = acc_re + pr;
+                acc_im = acc_im + pi;
+            }
+        }
+        if (live) {
+            floatx2 *dst = reinterpret_cast<floatx2 *>(a.beams) +
+                           (((uint64_t)c * a.nt16_total + tex_g) * a.B + b) * 16u + t_in;
+            *dst = floatx2{acc_re, acc_im};
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // One coefficient per lane (the launch shape of the reference's
 // calculate_beamweights_naive, BeamformerKernels.cu:7-52): every lane redoes the
 // per-pair terms.  grid = (ceil(n_pairs/256), min(nc, 65535)).
@@ -704,4 +808,27 @@ hipError_t bf_warm_module()
 {
     hipFuncAttributes attr;
     return hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(&bf_gather_beams_kernel));
+}
+
+hipError_t bf_launch_bform_terms(const bf_bform_terms_args &a, hipStream_t stream)
+{
+    if (a.nt == 0 || a.n_pairs == 0) return hipSuccess;
+    if (a.nt > 65535u || a.dt_dev == nullptr) return hipErrorInvalidValue;
+    const dim3 grid((a.n_pairs + kBlock - 1) / kBlock, a.nt);
+    hipLaunchKernelGGL(bf_bform_terms_kernel, grid, dim3(kBlock), 0, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t bf_launch_beamform(const bf_beamform_args &a_in, hipStream_t stream)
+{
+    bf_beamform_args a = a_in;
+    if (a.A == 0 || a.B == 0 || a.C == 0 || a.nt16 == 0) return hipSuccess;
+    if (a.chan_per_block == 0) return hipErrorInvalidValue;
+    a.n_bgroups = (a.B + 15u) / 16u;
+    a.n_cblocks = (a.C + a.chan_per_block - 1) / a.chan_per_block;
+    const uint64_t blocks = (uint64_t)a.n_bgroups * a.n_cblocks * a.nt16;
+    const size_t lds = (size_t)a.A * 32u;
+    if (blocks > 0x7fffffffull || lds > 64u * 1024u) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(bf_beamform_kernel, dim3((uint32_t)blocks), dim3(kBlock), lds, stream, a);
+    return hipGetLastError();
 }

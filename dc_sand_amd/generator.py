@@ -99,6 +99,17 @@ class SteeringCoefficientGenerator:
             "dcs_bf_generate_slab",
         )
 
+    def generate_and_beamform(self, d_antenna, antenna_bytes: int, d_beams, beams_bytes: int, t0: int = 0,
+                              nt: int | None = None, stream=None) -> None:
+        """Fused coefficient generation + beamforming (run_kernel's COMBINED branch,
+        ``BeamformerCoefficientTest.cu:259-262``); the table is indexed [beam*A + antenna]."""
+        nt = self.params.NR_SAMPLES_PER_CHANNEL if nt is None else nt
+        check(
+            _lib.lib().dcs_bf_generate_and_beamform(c_void_p(self._h), int(t0), int(nt), c_void_p(int(d_antenna)), int(antenna_bytes),
+                                                    c_void_p(int(d_beams)), int(beams_bytes), _s(stream)),
+            "dcs_bf_generate_and_beamform",
+        )
+
     def set_tuning(self, form: int = 0, nontemporal: int = -1, chan_per_block: int = 0, tiles_per_block: int = 0,
                    waves_per_block: int = 0, rows_per_wave: int = 0, xcd_remap: int = -1, nomath: bool = False) -> None:
         """``struct dcs_bf_tuning``; ``set_tuning()`` restores the defaults."""

@@ -61,7 +61,7 @@ enum dcs_bf_kernel {
     DCS_BF_NAIVE = 0,
     DCS_BF_MULTIPLE_CHANNELS = 1,
     DCS_BF_MULTIPLE_CHANNELS_AND_TIMESTAMPS = 2,
-    DCS_BF_COMBINED_COEFF_GEN_AND_BEAMFORMER_SINGLE_CHANNEL = 3 /* DCS_ERR_UNSUPPORTED */
+    DCS_BF_COMBINED_COEFF_GEN_AND_BEAMFORMER_SINGLE_CHANNEL = 3 /* has its own entry point: dcs_bf_generate_and_beamform */
 };
 
 /* BCT.hpp:33-37 (enum SteeringCoefficientBitWidth). */
@@ -150,7 +150,8 @@ int dcs_bf_set_delays_from_global(dcs_bf_context *ctx, const void *d_global_tabl
  * (layout above, time index t0 first).  `kernel` keeps the reference's launch
  * shapes: NAIVE and MULTIPLE_CHANNELS issue one launch per time step from a
  * host loop (BCT.cu:230-250), MULTIPLE_CHANNELS_AND_TIMESTAMPS one launch for
- * all of them (BCT.cu:253-257).  NAIVE + B16 and COMBINED return
+ * all of them (BCT.cu:253-257).  NAIVE + B16 returns DCS_ERR_UNSUPPORTED (BCT.cu:40-44), and so does
+ * COMBINED here (it needs antenna data: dcs_bf_generate_and_beamform).
  * DCS_ERR_UNSUPPORTED (BCT.cu:40-50).  All variants compute the verifier's
  * arithmetic (BCT.cu:319-328) and agree bit for bit with each other. */
 int dcs_bf_generate(dcs_bf_context *ctx, int kernel, int bitwidth, uint64_t t0, uint32_t nt,
@@ -160,6 +161,21 @@ int dcs_bf_generate(dcs_bf_context *ctx, int kernel, int bitwidth, uint64_t t0, 
  * [c0, c0+nc) only; d_out is the slab tensor [nt][nc][stations][beams]. */
 int dcs_bf_generate_slab(dcs_bf_context *ctx, int bitwidth, uint64_t t0, uint32_t nt,
                          uint32_t c0, uint32_t nc, void *d_out, size_t out_bytes, void *stream);
+
+/* run_kernel(), COMBINED_COEFF_GEN_AND_BEAMFORMER_SINGLE_CHANNEL branch (BCT.cu:259-262;
+ * kernel BeamformerKernels.cu:192-367, doc BeamformerKernels.cuh:95-162; verifier
+ * BCT.cu:363-414) -- SURVEY.md section 8 f1, generalised from the reference's
+ * hard-wired 64 antennas x 16 beams to any shape.  For time indices
+ * [t0, t0+nt) (both multiples of 16 = INTERNAL_TIME_SAMPLES):
+ *   d_antenna: int8  [nr_channels][nt/16][nr_stations][16][2]   (BeamformerKernels.cuh:137-140)
+ *   d_beams  : float [nr_channels][nt/16][nr_beams][16][2]      (BeamformerKernels.cuh:141-143)
+ *   beams = sum over antennas, in antenna order, of (coeff.re*sample.re, coeff.im*sample.im)
+ * -- the reference's element-wise product (BeamformerKernels.cu:315-316), not a
+ * complex one.  For this entry point the delay table is indexed
+ * [beam * nr_stations + antenna] (BCT.cu:311; BeamformerKernels.cu:252).
+ * No coefficient tensor is materialised. */
+int dcs_bf_generate_and_beamform(dcs_bf_context *ctx, uint64_t t0, uint32_t nt, const int8_t *d_antenna,
+                                 size_t antenna_bytes, float *d_beams, size_t beams_bytes, void *stream);
 
 /* Launch-geometry knobs (all 0 / NULL = library defaults; DESIGN.md "launch
  * geometry").  Two forms of the MULTIPLE_CHANNELS_AND_TIMESTAMPS generator

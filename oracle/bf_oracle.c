@@ -277,6 +277,49 @@ void dcs_oracle_device_variant_a3(const struct dcs_oracle_params *p,
     }
 }
 
+/* BeamformerCoefficientTest.cu:198-204 */
+void dcs_oracle_simulate_antenna_data(int8_t *out, size_t nbytes)
+{
+    for (size_t i = 0; i < nbytes; i++) out[i] = (int8_t)i;
+}
+
+/* BeamformerCoefficientTest.cu:294-337 (ordering :311) + :363-414 */
+void dcs_oracle_beamform(const struct dcs_oracle_params *p,
+                         const struct dcs_oracle_delay_vals *delays, size_t nt,
+                         const int8_t *pi8InAntData, float *pfCorrectBeams)
+{
+    const size_t NR_CHANNELS = (size_t)p->nr_channels;
+    const size_t NR_STATIONS = (size_t)p->nr_stations;
+    const size_t NR_BEAMS = (size_t)p->nr_beams;
+    const size_t NR_SAMPLES_PER_CHANNEL = nt;
+    const size_t INTERNAL_TIME_SAMPLES = 16;
+    for (size_t c = 0; c < NR_CHANNELS; c++) {
+        for (size_t t_ex = 0; t_ex < NR_SAMPLES_PER_CHANNEL / INTERNAL_TIME_SAMPLES; t_ex++) {
+            for (size_t t_in = 0; t_in < INTERNAL_TIME_SAMPLES; t_in++) {
+                const size_t t = t_ex * INTERNAL_TIME_SAMPLES + t_in;
+                float fDeltaTime = dcs_oracle_delta_time(p, t, k_ref_zero);
+                for (size_t b = 0; b < NR_BEAMS; b++) {
+                    size_t iBeamIndex = c * NR_SAMPLES_PER_CHANNEL * NR_BEAMS + t_ex * NR_BEAMS * INTERNAL_TIME_SAMPLES + b * INTERNAL_TIME_SAMPLES + t_in;
+                    float fBeamSumReal = 0;
+                    float fBeamSumImag = 0;
+                    for (size_t a = 0; a < NR_STATIONS; a++) {
+                        float fRealSteeringCoeff, fImagSteeringCoeff;
+                        dcs_oracle_coeff(p, delays[b * NR_STATIONS + a], fDeltaTime, c,
+                                         &fRealSteeringCoeff, &fImagSteeringCoeff);
+                        size_t ulAntSampleIndex = 2 * (c * NR_SAMPLES_PER_CHANNEL * NR_STATIONS + t_ex * NR_STATIONS * INTERNAL_TIME_SAMPLES + a * INTERNAL_TIME_SAMPLES + t_in);
+                        int8_t iRealAntSample = pi8InAntData[ulAntSampleIndex];
+                        int8_t iImagAntSample = pi8InAntData[ulAntSampleIndex + 1];
+                        fBeamSumReal += fRealSteeringCoeff * iRealAntSample;
+                        fBeamSumImag += fImagSteeringCoeff * iImagAntSample;
+                    }
+                    pfCorrectBeams[2 * iBeamIndex] = fBeamSumReal;
+                    pfCorrectBeams[2 * iBeamIndex + 1] = fBeamSumImag;
+                }
+            }
+        }
+    }
+}
+
 /* IEEE binary16 round-to-nearest-even of an fp32 (what __floats2half2_rn does
  * per element, BeamformerKernels.cu:113,182). */
 uint16_t dcs_oracle_f32_to_f16_rn(float x)

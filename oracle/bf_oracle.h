@@ -118,6 +118,21 @@ void dcs_oracle_device_variant_a3(const struct dcs_oracle_params *p,
                                   const struct dcs_oracle_delay_vals *delays,
                                   size_t t0, size_t nt, float *out);
 
+/* ---- fused coefficient generation + beamforming -------------
+ * BeamformerCoefficientTest.cu:198-204 -- synthetic antenna data: byte i = (int8_t)i.
+ * Layout [chan][time/16][station][16][2] (BeamformerKernels.cuh:137-143). */
+void dcs_oracle_simulate_antenna_data(int8_t *out, size_t nbytes);
+
+/* BeamformerCoefficientTest.cu:294-337 with the fused kernel's table ordering
+ * iAntBeamOrdering = b*NR_STATIONS + a (:311), then :363-414: for every
+ * (chan, time/16, beam, time%16) the fp32 sums over antennas, in antenna
+ * order, of coeff.re * sample.re and coeff.im * sample.im (an element-wise
+ * product, NOT a complex one -- :391-392).  delays is indexed [b*A + a].
+ * out: float [chan][nt/16][beam][16][2]; nt must be a multiple of 16. */
+void dcs_oracle_beamform(const struct dcs_oracle_params *p,
+                         const struct dcs_oracle_delay_vals *delays, size_t nt,
+                         const int8_t *antenna_data, float *out);
+
 /* fp16 (f2): IEEE binary16 round-to-nearest-even of an fp32, as
  * __floats2half2_rn does per element (BeamformerKernels.cu:113,182). */
 uint16_t dcs_oracle_f32_to_f16_rn(float x);

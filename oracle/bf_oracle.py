@@ -76,6 +76,8 @@ def lib() -> ctypes.CDLL:
         L.dcs_oracle_max_ulp.argtypes = [c_void_p, c_void_p, c_size_t, c_uint32, POINTER(c_uint64), POINTER(c_int64)]
         L.dcs_oracle_max_ulp.restype = c_uint32
         L.dcs_oracle_device_variant_a3.argtypes = [P, c_void_p, c_size_t, c_size_t, c_void_p]
+        L.dcs_oracle_simulate_antenna_data.argtypes = [c_void_p, c_size_t]
+        L.dcs_oracle_beamform.argtypes = [P, c_void_p, c_size_t, c_void_p, c_void_p]
         L.dcs_oracle_f32_to_f16_rn.argtypes = [c_float]
         L.dcs_oracle_f32_to_f16_rn.restype = c_uint16
         _LIB = L
@@ -156,6 +158,24 @@ def device_variant_a3(p: OracleParams, delays: np.ndarray, t0=0, nt=1) -> np.nda
     delays = np.ascontiguousarray(delays, dtype=delay_vals_dtype)
     out = np.empty((nt, p.nr_channels, p.nr_stations, p.nr_beams, 2), dtype=np.float32)
     lib().dcs_oracle_device_variant_a3(byref(p), c_void_p(delays.ctypes.data), t0, nt, c_void_p(out.ctypes.data))
+    return out
+
+
+def simulate_antenna_data(p: OracleParams, nt: int) -> np.ndarray:
+    """int8 [chan][nt/16][station][16][2], byte i = (int8)i (BeamformerCoefficientTest.cu:198-204)."""
+    out = np.empty((p.nr_channels, nt // 16, p.nr_stations, 16, 2), dtype=np.int8)
+    lib().dcs_oracle_simulate_antenna_data(c_void_p(out.ctypes.data), out.nbytes)
+    return out
+
+
+def beamform(p: OracleParams, delays_beam_major: np.ndarray, nt: int, antenna_data: np.ndarray) -> np.ndarray:
+    """Expected beams float [chan][nt/16][beam][16][2]; delays indexed [b*A + a]."""
+    assert nt % 16 == 0
+    delays = np.ascontiguousarray(delays_beam_major, dtype=delay_vals_dtype)
+    ant = np.ascontiguousarray(antenna_data, dtype=np.int8)
+    assert ant.size == p.nr_channels * nt * p.nr_stations * 2
+    out = np.empty((p.nr_channels, nt // 16, p.nr_beams, 16, 2), dtype=np.float32)
+    lib().dcs_oracle_beamform(byref(p), c_void_p(delays.ctypes.data), nt, c_void_p(ant.ctypes.data), c_void_p(out.ctypes.data))
     return out
 
 

@@ -213,8 +213,11 @@ def test_error_behaviour(gpu):
         g.generate(buf, buf.nbytes, kernel=0, bitwidth=0)
     assert e.value.status == _lib.DCS_ERR_UNSUPPORTED
     with pytest.raises(_lib.DcsError) as e:
-        g.generate(buf, buf.nbytes, kernel=3)
+        g.generate(buf, buf.nbytes, kernel=3)  # the fused kernel has its own entry point
     assert e.value.status == _lib.DCS_ERR_UNSUPPORTED
+    with pytest.raises(_lib.DcsError) as e:
+        g.generate_and_beamform(buf, 8, buf, 8, t0=0, nt=8)  # not a multiple of 16
+    assert e.value.status == _lib.DCS_ERR_INVALID_ARGUMENT
     with pytest.raises(_lib.DcsError) as e:
         g.generate(buf, buf.nbytes - 1)
     assert e.value.status == _lib.DCS_ERR_INVALID_ARGUMENT
@@ -408,4 +411,75 @@ def test_streaming_graph_ticks_with_table_updates(gpu, oracle):
         mx, n_over, first = oracle.max_ulp(host, exp, 1)
         assert n_over == 0, (tick, t, mx, first)
     st.end()
+    g.close()
+
+
+@pytest.mark.parametrize("A,B,C,nt,seeded", [(64, 16, 64, 256, False), (64, 16, 64, 32, True), (8, 4, 5, 16, True),
+                                             (37, 21, 9, 48, True), (130, 3, 4, 16, True), (4, 40, 7, 32, True)])
+def test_fused_coefficient_generation_and_beamforming(gpu, oracle, A, B, C, nt, seeded):
+    """beams = sum over antennas (in order) of the element-wise product of
+    coefficient and int8 sample, against the verifier restatement
+    (BeamformerCoefficientTest.cu:363-414).  The reference's tolerance is 1e-1
+    (runBeamformerTests.cpp:15); the summation order is the verifier's, so the only
+    difference is each coefficient's <= 1 ULP: |diff| <= sum|sample| * 2^-23 ~ 2e-3
+    at 64 antennas; asserted at 2e-5 * A (and at the reference's 1e-1)."""
+    from dc_sand_amd import BeamformerParameters
+    from dc_sand_amd.generator import SteeringCoefficientGenerator, simulate_input
+
+    bp = BeamformerParameters(NR_CHANNELS=C, NR_STATIONS=A, NR_BEAMS=B, NR_SAMPLES_PER_CHANNEL=nt)
+    op = oracle.params_from(bp)
+    table = rand_table(bp.n_pairs, seed=A + B) if seeded else simulate_input(bp)  # indexed [b*A + a] by this kernel
+    ant = oracle.simulate_antenna_data(op, nt)
+    if seeded:
+        ant = np.random.default_rng(A).integers(-128, 128, size=ant.shape, dtype=np.int8)
+    exp = oracle.beamform(op, table, nt, ant)
+    g = SteeringCoefficientGenerator(bp)
+    g.upload_delays(table)
+    d_ant = gpu.mem_alloc(ant.nbytes)
+    gpu.memcpy_htod(d_ant, ant)
+    d_beams = gpu.mem_alloc(exp.nbytes + 64)
+    gpu.memset(d_beams, 0xFF, exp.nbytes + 64)
+    g.generate_and_beamform(d_ant, ant.nbytes, d_beams, exp.nbytes, t0=0, nt=nt)
+    host = np.empty(exp.nbytes + 64, dtype=np.uint8)
+    gpu.memcpy_dtoh(host, d_beams)
+    assert np.all(host[exp.nbytes:] == 0xFF)
+    got = host[:exp.nbytes].view(np.float32).reshape(exp.shape)
+    diff = np.abs(got - exp)
+    assert np.all(np.isfinite(got))
+    assert diff.max() <= 2e-5 * A + 1e-6, diff.max()
+    assert oracle.compare(got, exp, 1e-1) == -1
+    g.close()
+
+
+def test_fused_harness_and_slow_path(gpu, oracle):
+    from dc_sand_amd import BeamformerParameters
+    from dc_sand_amd.beamformer_coeff_test import BeamformerCoeffTest, SteeringCoefficientBitWidth as BW, SteeringCoefficientKernel as K
+    from dc_sand_amd.generator import SteeringCoefficientGenerator
+
+    def beam_verifier(bp, delays, nt, ant):
+        return oracle.beamform(oracle.params_from(bp), np.asarray(delays), nt, ant)
+
+    t = BeamformerCoeffTest(1e-1, K.COMBINED_COEFF_GEN_AND_BEAMFORMER_SINGLE_CHANNEL, BW.b32, beam_verifier=beam_verifier, verbose=False)
+    t.run_test()
+    assert t.get_result() == 1 and t.max_abs_diff < 2e-3
+    assert t.get_time() > 0
+    with pytest.raises(ValueError):
+        BeamformerCoeffTest(1e-1, K.COMBINED_COEFF_GEN_AND_BEAMFORMER_SINGLE_CHANNEL, BW.b16)
+    # a pair outside the fast path's range sends its 16-sample blocks down the slow branch
+    bp = BeamformerParameters(NR_CHANNELS=6, NR_STATIONS=9, NR_BEAMS=5, NR_SAMPLES_PER_CHANNEL=32)
+    op = oracle.params_from(bp)
+    table = rand_table(bp.n_pairs, seed=77)
+    table["fDelayRate_sps"][11] = 1e-2
+    table["fDelayRate_sps"][12] = 1e-30
+    ant = np.random.default_rng(3).integers(-128, 128, size=(6, 2, 9, 16, 2), dtype=np.int8)
+    exp = oracle.beamform(op, table, 32, ant)
+    g = SteeringCoefficientGenerator(bp)
+    g.upload_delays(table)
+    d_ant = gpu.mem_alloc(ant.nbytes)
+    gpu.memcpy_htod(d_ant, ant)
+    d_beams = gpu.mem_alloc(exp.nbytes)
+    g.generate_and_beamform(d_ant, ant.nbytes, d_beams, exp.nbytes, t0=0, nt=32)
+    got = np.empty_like(exp)
+    gpu.memcpy_dtoh(got, d_beams)
+    assert np.abs(got - exp).max() <= 2e-4 * 9
     g.close()
