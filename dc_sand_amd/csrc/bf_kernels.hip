@@ -50,7 +50,11 @@ __device__ __forceinline__ void coeff_fast(const float fRate, const float fPhase
                                            const float D, const float y, float &re, float &im)
 {
     const float rot = dcs_rotation(fRate, fPhase0, fChan, D, y);
+#ifdef DCS_USE_OCML_SINCOS // A/B build only (tools/sincos_ab.py): __ocml_sincos_f32
+    sincosf(rot, &im, &re);
+#else
     dcs_sincos_fast(rot, &im, &re);
+#endif
 }
 
 // Slow path: hardware-sequence IEEE divide and fp64 sincos rounded once to
