@@ -59,7 +59,7 @@ __device__ __forceinline__ void coeff_fast(const float fRate, const float fPhase
 
 // Slow path: hardware-sequence IEEE divide and fp64 sincos rounded once to
 // fp32, i.e. the verifier's own definition (BeamformerCoefficientTest.cu:327-328).
-__device__ __noinline__ void coeff_slow(const float fRate, const float fPhase0, const float fChan,
+__device__ __forceinline__ void coeff_slow(const float fRate, const float fPhase0, const float fChan,
                                         const float D, float &re, float &im)
 {
     const float rot = dcs_rotation_ieee(fRate, fPhase0, fChan, D);

@@ -1,0 +1,141 @@
+// run_beamformer_tests.cpp -- the reference's runBeamformerTests executable
+// (beamformer_coefficient_generator/runBeamformerTests.cpp:10-82) written against
+// the C-ABI, in the reference's own language: a UnitTest-shaped C++ host
+// (common/UnitTest.cpp:28-59) whose five phases call libdcs_beamformer.so, with the
+// C oracle (test infrastructure) as verify_output()'s expected data.
+// Build: tests/cpp/Makefile.  Needs an MI355X.  Exit code 0 / 1 like the reference.
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <string>
+#include <vector>
+
+#include "../../include/dcs_beamformer.h"
+#include "../../oracle/bf_oracle.h"
+
+#define DCS_ERRCHK(x)                                                                        \
+    {                                                                                        \
+        int s_ = (x);                                                                        \
+        if (s_) {                                                                            \
+            std::fprintf(stderr, "%s %s:%d\n", dcs_error_string(s_), __FILE__, __LINE__);    \
+            std::exit(s_ > 0 ? s_ : 1);                                                      \
+        }                                                                                    \
+    } // = GPU_ERRCHK, common/Utils.hpp:8
+
+struct CoeffTest { // BeamformerCoeffTest for the three coefficient kernels, fp32
+    dcs_bf_params p;
+    int kernel;
+    float tol;
+    dcs_bf_context *ctx = nullptr;
+    dcs_delay_vals *hDelays = nullptr;
+    float *hCoeffs = nullptr;
+    void *dCoeffs = nullptr;
+    size_t coeffBytes = 0;
+    int result = 0; // UnitTest::m_iResult: 1 pass, -1 fail, 0 not run
+    float htod_ms = 0, kernel_ms = 0, dtoh_ms = 0;
+    uint32_t max_ulp = 0;
+
+    CoeffTest(float tolerance, int kernelOption) : kernel(kernelOption), tol(tolerance)
+    {
+        DCS_ERRCHK(dcs_bf_default_params(&p));
+        DCS_ERRCHK(dcs_bf_output_bytes(&p, DCS_BF_B32, (uint32_t)p.nr_samples_per_channel, &coeffBytes));
+        const size_t n = (size_t)p.nr_stations * p.nr_beams;
+        DCS_ERRCHK(dcs_host_alloc((void **)&hDelays, n * sizeof(dcs_delay_vals)));
+        DCS_ERRCHK(dcs_host_alloc((void **)&hCoeffs, coeffBytes));
+        DCS_ERRCHK(dcs_malloc(&dCoeffs, coeffBytes));
+        DCS_ERRCHK(dcs_bf_create(&p, &ctx));
+    }
+    ~CoeffTest()
+    {
+        dcs_bf_destroy(ctx);
+        dcs_free(dCoeffs);
+        dcs_host_free(hCoeffs);
+        dcs_host_free(hDelays);
+    }
+    void simulate_input() { DCS_ERRCHK(dcs_bf_simulate_input(&p, hDelays)); }
+    void transfer_HtoD() { DCS_ERRCHK(dcs_bf_upload_delays(ctx, hDelays, nullptr)); }
+    void run_kernel()
+    {
+        DCS_ERRCHK(dcs_bf_generate(ctx, kernel, DCS_BF_B32, 0, (uint32_t)p.nr_samples_per_channel, dCoeffs, coeffBytes, nullptr));
+    }
+    void transfer_DtoH()
+    {
+        DCS_ERRCHK(dcs_memcpy_dtoh(hCoeffs, dCoeffs, coeffBytes, nullptr));
+        DCS_ERRCHK(dcs_stream_synchronize(nullptr));
+    }
+    void verify_output()
+    {
+        dcs_oracle_params op = {p.nr_channels, p.nr_stations, p.nr_beams, p.sampling_period, p.fft_size};
+        std::vector<float> expect(coeffBytes / sizeof(float));
+        const double cpu_s = dcs_oracle_generate(&op, (const dcs_oracle_delay_vals *)hDelays, 0, (size_t)p.nr_samples_per_channel, 0,
+                                                 (size_t)p.nr_channels, expect.data());
+        std::printf("CPU took %g ms to generate correct steering coefficients.\n", cpu_s * 1e3);
+        const int64_t bad = dcs_oracle_compare(hCoeffs, expect.data(), expect.size(), tol);
+        if (bad >= 0) {
+            std::printf("Index: %lld. Generated Value: %g. Correct Value: %g\n", (long long)bad, hCoeffs[bad], expect[bad]);
+            result = -1;
+            return;
+        }
+        uint64_t n_over = 0;
+        int64_t first = -1;
+        max_ulp = dcs_oracle_max_ulp(hCoeffs, expect.data(), expect.size(), 1, &n_over, &first);
+        result = n_over == 0 ? 1 : -1;
+    }
+    void run_test() // UnitTest::run_test, common/UnitTest.cpp:28-59
+    {
+        void *e[6];
+        for (auto &ev : e) DCS_ERRCHK(dcs_event_create(&ev));
+        simulate_input();
+        DCS_ERRCHK(dcs_event_record(e[0], nullptr));
+        transfer_HtoD();
+        DCS_ERRCHK(dcs_event_record(e[1], nullptr));
+        DCS_ERRCHK(dcs_event_synchronize(e[1]));
+        DCS_ERRCHK(dcs_event_elapsed_ms(e[0], e[1], &htod_ms));
+        DCS_ERRCHK(dcs_event_record(e[2], nullptr));
+        run_kernel();
+        DCS_ERRCHK(dcs_event_record(e[3], nullptr));
+        DCS_ERRCHK(dcs_event_synchronize(e[3]));
+        DCS_ERRCHK(dcs_event_elapsed_ms(e[2], e[3], &kernel_ms));
+        DCS_ERRCHK(dcs_event_record(e[4], nullptr));
+        transfer_DtoH();
+        DCS_ERRCHK(dcs_event_record(e[5], nullptr));
+        DCS_ERRCHK(dcs_event_synchronize(e[5]));
+        DCS_ERRCHK(dcs_event_elapsed_ms(e[4], e[5], &dtoh_ms));
+        verify_output();
+        for (auto &ev : e) dcs_event_destroy(ev);
+    }
+};
+
+int main()
+{
+    int ndev = 0;
+    DCS_ERRCHK(dcs_device_count(&ndev));
+    if (ndev < 1) {
+        std::fprintf(stderr, "no HIP device\n");
+        return 1;
+    }
+    struct Case {
+        const char *name;
+        int kernel;
+        float tol;
+    } cases[] = {
+        {"Multiple Chans+Timestamps", DCS_BF_MULTIPLE_CHANNELS_AND_TIMESTAMPS, 1e-4f}, // runBeamformerTests.cpp:30
+        {"Multiple Channels", DCS_BF_MULTIPLE_CHANNELS, 1e-4f},
+        {"Naive Implementation", DCS_BF_NAIVE, 1e-4f}, // :61
+    };
+    std::printf("%-50s%-20s%-20s%-10s\n", "Kernel Name", "GPU Utilisation", "GPU Utilisation", "max ULP");
+    for (const Case &c : cases) {
+        CoeffTest t(c.tol, c.kernel);
+        t.run_test();
+        if (t.result != 1) {
+            std::printf("Test failed, output data not generated correctly\n");
+            return 1;
+        }
+        float util[2];
+        DCS_ERRCHK(dcs_bf_gpu_utilisation(&t.p, t.kernel_ms, util));
+        std::printf("%-50s%-20g%-20g%-10u (HtoD %.3f ms, kernel %.3f ms, DtoH %.3f ms)\n", c.name, util[0], util[1], t.max_ulp, t.htod_ms,
+                    t.kernel_ms, t.dtoh_ms);
+    }
+    return 0;
+}

@@ -483,3 +483,60 @@ def test_fused_harness_and_slow_path(gpu, oracle):
     gpu.memcpy_dtoh(got, d_beams)
     assert np.abs(got - exp).max() <= 2e-4 * 9
     g.close()
+
+
+def test_config4_one_rank_shard_at_full_size(gpu, oracle):
+    """BASELINE configs[3]: 256 ant x 4096 beam x 32768 chan beam-sharded over 8 GPUs.
+    One rank's share at FULL size on this GPU (rank 3: beams [1536, 2048), 2^32
+    coefficients, 32 GiB): the slice is gathered on the device from the 16 MiB global
+    table, the tensor is sampled against the oracle's column slab, and its whole-tensor
+    properties are checked on the device."""
+    from dc_sand_amd import BeamformerParameters
+    from dc_sand_amd.generator import SteeringCoefficientGenerator
+    from dc_sand_amd.sharding import beam_range, local_parameters, slice_table
+
+    gp = BeamformerParameters(NR_CHANNELS=32768, NR_STATIONS=256, NR_BEAMS=4096)
+    sh = beam_range(gp.NR_BEAMS, 8, 3)
+    assert (sh.beam_lo, sh.beam_hi) == (1536, 2048)
+    lp = local_parameters(gp, sh)
+    glob = rand_table(gp.n_pairs, seed=44)
+    assert glob.nbytes == 16 * 2 ** 20
+    d_glob = gpu.mem_alloc(glob.nbytes)
+    gpu.memcpy_htod(d_glob, glob)
+    g = SteeringCoefficientGenerator(lp)
+    g.set_delays_from_global(d_glob, gp.NR_BEAMS, sh.beam_lo)
+    nbytes = g.output_bytes(1, 1)
+    assert nbytes == 32 * 2 ** 30
+    buf = gpu.mem_alloc(nbytes)
+    t = 18
+    g.generate(buf, nbytes, t0=t, nt=1)
+    local = slice_table(glob, gp, sh)
+    op = oracle.params_from(lp)
+    row = lp.n_pairs * 8
+    host = np.empty((lp.NR_STATIONS, lp.NR_BEAMS, 2), dtype=np.float32)
+    for c in (0, 1, 12345, 16384, 32767):
+        gpu.memcpy_dtoh(host, int(buf) + c * row)  # byte offsets beyond 2^32
+        exp = oracle.generate(op, local, t, 1, c, 1)
+        mx, n_over, first = oracle.max_ulp(host, exp, 1)
+        assert n_over == 0, (c, mx, first)
+    ck, dev = gpu.tensor_properties(buf, nbytes)
+    assert dev < 4e-7
+    g.close()
+    buf.free()
+
+
+def test_cpp_host_against_c_abi(gpu):
+    """The reference's harness is C++: tests/cpp/run_beamformer_tests.cpp is the
+    runBeamformerTests executable written against the C-ABI (plain g++, no hipcc
+    on the host side), with the C oracle as verify_output's expected data."""
+    import subprocess
+    from pathlib import Path
+
+    d = Path(__file__).resolve().parent / "cpp"
+    res = subprocess.run(["make", "-C", str(d)], capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr
+    run = subprocess.run([str(d / "run_beamformer_tests")], capture_output=True, text=True, timeout=600)
+    assert run.returncode == 0, run.stdout + run.stderr
+    assert run.stdout.count("CPU took") == 3
+    for name in ("Multiple Chans+Timestamps", "Multiple Channels", "Naive Implementation"):
+        assert name in run.stdout
