@@ -46,6 +46,7 @@ def parse():
     ap.add_argument("--beams-per-gpu", type=int, default=BEAMS_PER_GPU)
     ap.add_argument("--chan", type=int, default=CHAN)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-autotune", action="store_true", help="keep the library's default launch geometry")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline sample time")
     # rehearsal of the N > 1 control flow on a box with fewer GPUs than ranks (never a result):
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="nccl = RCCL over xGMI (the product path)")
@@ -172,6 +173,14 @@ def main():
         device.memset(out.data_ptr(), 0, out_bytes, stream=sh)
     torch.cuda.synchronize()
 
+    # untimed set-up: let the library measure its launch geometries on this device for
+    # this shape (dcs_bf_autotune; every geometry gives the same bits)
+    tuning = None
+    if not args.no_autotune:
+        gen.upload_delays(np.ascontiguousarray(simulate_input(bp)), stream=sh)
+        tuning = gen.autotune(out.data_ptr(), out_bytes, stream=sh)
+        torch.cuda.synchronize()
+
     for b in range(2):
         freed[b].record(main_stream)
     prefetch(0)
@@ -250,7 +259,9 @@ def main():
                             f"beam-sharded {args.beams_per_gpu} beams/GPU" + (f", {args.backend} bcast of the delay table each step" if N > 1 else ""),
                 "coeffs_per_step": coeffs_per_gpu_step * N,
                 "output_bytes_per_gpu_step": out_bytes,
-                "kernel": "MULTIPLE_CHANNELS_AND_TIMESTAMPS (tiled form, library defaults)",
+                "kernel": "MULTIPLE_CHANNELS_AND_TIMESTAMPS (tiled form)",
+                "launch_geometry": ({k: tuning[k] for k in ("tiles_per_block", "chan_per_block", "nontemporal")} if tuning
+                                    else "library defaults"),
                 "collective": ("none" if N == 1 else ("RCCL broadcast" if args.backend == "nccl" else "gloo broadcast (REHEARSAL, not a result)")),
             },
             "roofline": {

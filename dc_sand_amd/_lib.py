@@ -79,6 +79,7 @@ SIGNATURES = [
     ("dcs_bf_generate", c_int, [_VP, c_int, c_int, c_uint64, c_uint32, _VP, c_size_t, _VP]),
     ("dcs_bf_generate_slab", c_int, [_VP, c_int, c_uint64, c_uint32, c_uint32, c_uint32, _VP, c_size_t, _VP]),
     ("dcs_bf_set_tuning", c_int, [_VP, _VP]),
+    ("dcs_bf_autotune", c_int, [_VP, c_int, _VP, c_size_t, _VP, _VP]),
     ("dcs_bf_generate_and_beamform", c_int, [_VP, c_uint64, c_uint32, _VP, c_size_t, _VP, c_size_t, _VP]),
     ("dcs_bf_gpu_utilisation", c_int, [POINTER(CParams), c_float, POINTER(c_float)]),
     ("dcs_bf_stream_begin", c_int, [_VP, c_int, c_uint32, c_uint32, _VP, c_size_t, _VP, POINTER(_VP)]),

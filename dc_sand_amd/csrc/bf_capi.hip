@@ -53,10 +53,29 @@ dcs_bf_consts make_consts(const dcs_bf_params *p)
     const double scale = (double)(p->nr_channels - 1) * 3.14159274101257324219 / (double)D;
     k.fRotBoundScale = (float)(scale * 1.0001) ;
     if (!(k.fRotBoundScale >= 0.0f)) k.fRotBoundScale = INFINITY;
+    k.uDiv3Exact = 0u; // set by verify_div3() once a device is at hand
+    k.fLowDegLimit = 500.0f;
     k.fPad = 0.0f;
     k.dHalfChannels = p->nr_channels / 2.0; // BeamformerCoefficientTest.cu:323
     k.dDenominator = (double)D;
     return k;
+}
+
+// Is the 3-op divide exact for this launch constant?  All 2^23 significands of one
+// binade on the device against the IEEE divide (bf_math.h: scale invariance).
+int verify_div3(dcs_bf_consts *k)
+{
+    uint32_t *d_cnt = nullptr;
+    uint32_t h_cnt = 1;
+    hipError_t e = hipMalloc((void **)&d_cnt, sizeof(uint32_t));
+    if (e != hipSuccess) return (int)e;
+    e = hipMemset(d_cnt, 0, sizeof(uint32_t));
+    if (e == hipSuccess) e = bf_launch_verify_div3(k->fDenominator, k->fRcpDenominator, d_cnt, nullptr);
+    if (e == hipSuccess) e = hipMemcpy(&h_cnt, d_cnt, sizeof(uint32_t), hipMemcpyDeviceToHost);
+    (void)hipFree(d_cnt);
+    if (e != hipSuccess) return (int)e;
+    k->uDiv3Exact = (h_cnt == 0u) ? 1u : 0u;
+    return DCS_OK;
 }
 
 } // namespace
@@ -66,6 +85,7 @@ struct dcs_bf_context {
     dcs_bf_consts k;
     uint32_t n_pairs;
     int device;
+    uint32_t div3_verified; // what verify_div3 found for this context's divisor
     dcs_delay_vals *d_table[2]; // double-buffered compact table
     int cur;                    // buffer generate reads
     bool table_set;
@@ -304,7 +324,9 @@ int dcs_bf_create(const dcs_bf_params *p, dcs_bf_context **out)
         // first use of the pinned->device copy path costs ~0.25 ms once: pay it here,
         // not inside the caller's first timed launch
         c->h_dt[0] = 0.0f;
-        st = (int)hipMemcpy(c->d_dt, c->h_dt, sizeof(float), hipMemcpyHostToDevice);
+        if ((st = (int)hipMemcpy(c->d_dt, c->h_dt, sizeof(float), hipMemcpyHostToDevice)) != 0) break;
+        if ((st = verify_div3(&c->k)) != 0) break;
+        c->div3_verified = c->k.uDiv3Exact;
     } while (0);
     if (st != 0) {
         dcs_bf_destroy(c);
@@ -361,6 +383,8 @@ int dcs_bf_set_tuning(dcs_bf_context *c, const dcs_bf_tuning *t)
     if (!t) { // back to the defaults
         std::memset(&c->tune, 0, sizeof(c->tune));
         c->tune.nontemporal = -1;
+        c->k.uDiv3Exact = c->div3_verified;
+        c->k.fLowDegLimit = 500.0f;
         return DCS_OK;
     }
     if (t->form < 0 || t->form > 2) return DCS_ERR_INVALID_ARGUMENT;
@@ -373,7 +397,11 @@ int dcs_bf_set_tuning(dcs_bf_context *c, const dcs_bf_tuning *t)
     if (t->rows_per_wave != 0 && t->rows_per_wave != 1 && t->rows_per_wave != 2 && t->rows_per_wave != 4)
         return DCS_ERR_INVALID_ARGUMENT;
     if (t->xcd_remap < -1 || t->xcd_remap > 1) return DCS_ERR_INVALID_ARGUMENT;
+    if (t->math_mode < 0 || t->math_mode > 3) return DCS_ERR_INVALID_ARGUMENT;
     c->tune = *t;
+    // math_mode bit 0: keep the 5-op divide; bit 1: keep the full polynomials
+    c->k.uDiv3Exact = (t->math_mode & 1) ? 0u : c->div3_verified;
+    c->k.fLowDegLimit = (t->math_mode & 2) ? 0.0f : 500.0f;
     return DCS_OK;
 }
 
@@ -382,16 +410,17 @@ namespace {
 // Defaults: see DESIGN.md "launch geometry" (measured on MI355X at
 // 64 x 1024 x 32768, profiles/r01_geometry_sweep.md).  The write rate the HBM
 // system sustains falls with the number of stores a wave issues before it
-// retires, so the walk is kept SHORT: 4 channel rows per wave.
-//   fp32: 1 tile x 16 channels per workgroup (4 stores per wave), nontemporal;
-//   fp16: 4 tiles x 32 channels per workgroup (VALU-bound form).
+// retires, so the fp32 walk is kept SHORT; the optimum is sharp and moves with
+// the arithmetic's speed (dcs_bf_autotune re-measures it for a given shape):
+//   fp32: 1 tile x 14 channels per workgroup (3-4 stores per wave), nontemporal;
+//   fp16: 1 tile x 128 channels per workgroup (VALU-bound: amortise the set-up).
 void pick_geometry(const dcs_bf_context *c, bool out16, uint32_t nc, uint32_t nt, int *tpb, uint32_t *cpb, bool *ntstore)
 {
     (void)nc;
     (void)nt;
-    *tpb = c->tune.tiles_per_block ? c->tune.tiles_per_block : (out16 ? 4 : 1);
+    *tpb = c->tune.tiles_per_block ? c->tune.tiles_per_block : 1;
     *ntstore = c->tune.nontemporal < 0 ? true : c->tune.nontemporal != 0;
-    *cpb = c->tune.chan_per_block ? (uint32_t)c->tune.chan_per_block : (out16 ? 32u : 16u);
+    *cpb = c->tune.chan_per_block ? (uint32_t)c->tune.chan_per_block : (out16 ? 128u : 14u);
 }
 
 int prepare_tiled(dcs_bf_context *c, bool out16, const float *dt_dev, float dt0, uint32_t nt, uint32_t c0,
@@ -456,6 +485,7 @@ int launch_rows(dcs_bf_context *c, bool out16, const float *dt_dev, float dt0, u
     a.nt = nt;
     a.D = c->k.fDenominator;
     a.y = c->k.fRcpDenominator;
+    a.div3 = c->k.uDiv3Exact;
     const int nw = c->tune.waves_per_block ? c->tune.waves_per_block : 4;
     const int rpw = c->tune.rows_per_wave ? c->tune.rows_per_wave : (out16 ? 4 : 2);
     const bool ntstore = c->tune.nontemporal < 0 ? true : c->tune.nontemporal != 0;
@@ -628,6 +658,68 @@ int dcs_bf_generate_and_beamform(dcs_bf_context *c, uint64_t t0, uint32_t nt, co
     return DCS_OK;
 }
 
+int dcs_bf_autotune(dcs_bf_context *c, int bitwidth, void *d_out, size_t out_bytes, void *stream,
+                    dcs_bf_tuning *chosen)
+{
+    if (!c || !d_out) return DCS_ERR_INVALID_ARGUMENT;
+    if (bitwidth != DCS_BF_B16 && bitwidth != DCS_BF_B32) return DCS_ERR_INVALID_ARGUMENT;
+    if (!c->table_set) return DCS_ERR_NOT_READY;
+    const bool out16 = bitwidth == DCS_BF_B16;
+    const size_t row = (size_t)c->n_pairs * (out16 ? 4u : 8u);
+    uint64_t nc64 = out_bytes / row;
+    if (nc64 > (uint64_t)c->p.nr_channels) nc64 = (uint64_t)c->p.nr_channels;
+    if (nc64 == 0) return DCS_ERR_INVALID_ARGUMENT;
+    const uint32_t nc = (uint32_t)nc64;
+    hipStream_t s = as_stream(stream);
+
+    struct cand { int tpb, cpb; double best_ms; };
+    static const int k32[][2] = {{1, 8}, {1, 10}, {1, 12}, {1, 13}, {1, 14}, {1, 15}, {1, 16}, {1, 18}, {1, 20}, {1, 24},
+                                 {1, 32}, {2, 8}, {2, 12}, {2, 16}, {4, 4}, {4, 8}, {4, 16}};
+    static const int k16[][2] = {{1, 32}, {1, 64}, {1, 96}, {1, 128}, {1, 192}, {1, 256}, {2, 32}, {2, 64},
+                                 {4, 16}, {4, 32}, {4, 40}, {4, 48}, {4, 64}};
+    const int(*tab)[2] = out16 ? k16 : k32;
+    const int ncand = out16 ? (int)(sizeof(k16) / sizeof(k16[0])) : (int)(sizeof(k32) / sizeof(k32[0]));
+    cand cands[32];
+    for (int i = 0; i < ncand; i++) cands[i] = {tab[i][0], tab[i][1], 1e30};
+
+    const dcs_bf_tuning saved = c->tune;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    int st = (int)hipEventCreate(&e0);
+    if (st == 0) st = (int)hipEventCreate(&e1);
+    // settle the clocks on the current setting, then three interleaved rounds;
+    // a candidate's score is its best round (3 launches per round, one event pair)
+    for (int i = 0; i < 10 && st == 0; i++) st = dcs_bf_generate_slab(c, bitwidth, 1, 1, 0, nc, d_out, out_bytes, stream);
+    for (int rnd = 0; rnd < 3 && st == 0; rnd++) {
+        for (int i = 0; i < ncand && st == 0; i++) {
+            c->tune.form = 1;
+            c->tune.tiles_per_block = cands[i].tpb;
+            c->tune.chan_per_block = cands[i].cpb;
+            c->tune.nontemporal = 1;
+            st = dcs_bf_generate_slab(c, bitwidth, 1, 1, 0, nc, d_out, out_bytes, stream); // untimed
+            if (st == 0) st = (int)hipEventRecord(e0, s);
+            for (int k = 0; k < 3 && st == 0; k++) st = dcs_bf_generate_slab(c, bitwidth, 1, 1, 0, nc, d_out, out_bytes, stream);
+            if (st == 0) st = (int)hipEventRecord(e1, s);
+            if (st == 0) st = (int)hipEventSynchronize(e1);
+            float ms = 0.0f;
+            if (st == 0) st = (int)hipEventElapsedTime(&ms, e0, e1);
+            if (st == 0 && ms / 3.0 < cands[i].best_ms) cands[i].best_ms = ms / 3.0;
+        }
+    }
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    c->tune = saved;
+    if (st != 0) return st;
+    int best = 0;
+    for (int i = 1; i < ncand; i++)
+        if (cands[i].best_ms < cands[best].best_ms) best = i;
+    c->tune.form = 1;
+    c->tune.tiles_per_block = cands[best].tpb;
+    c->tune.chan_per_block = cands[best].cpb;
+    c->tune.nontemporal = 1;
+    if (chosen) *chosen = c->tune;
+    return DCS_OK;
+}
+
 int dcs_bf_gpu_utilisation(const dcs_bf_params *p, float kernel_ms, float out[2])
 {
     if (!params_ok(p) || !out) return DCS_ERR_INVALID_ARGUMENT;
@@ -739,7 +831,7 @@ int dcs_bf_stream_end(dcs_bf_stream *s)
 /* ---- probes ------------------------------------------------------------- */
 int dcs_probe_sincos(int which, const float *d_x, size_t n, float *d_sin, float *d_cos, void *stream)
 {
-    if (which < 0 || which > 2 || (n && (!d_x || !d_sin || !d_cos))) return DCS_ERR_INVALID_ARGUMENT;
+    if (which < 0 || which > 3 || (n && (!d_x || !d_sin || !d_cos))) return DCS_ERR_INVALID_ARGUMENT;
     return (int)bf_launch_probe_sincos(which, d_x, n, d_sin, d_cos, as_stream(stream));
 }
 

@@ -59,6 +59,7 @@ struct bf_rows_args {
     uint32_t c0, nc, nt;
     uint32_t n_colgroups, n_rowgroups; // filled by the launcher
     uint32_t xcd_remap;
+    uint32_t div3; // dcs_bf_consts::uDiv3Exact
     float D, y;
 };
 hipError_t bf_launch_rows(const bf_rows_args &a, bool out16, int waves_per_block, int rows_per_wave,
@@ -115,5 +116,6 @@ hipError_t bf_launch_probe_pattern(void *out, uint32_t rows, uint32_t cols, uint
 #define BF_PROBE_REDUCE_WAVES 8192
 hipError_t bf_launch_probe_reduce(const void *in, size_t bytes, unsigned long long *d_part, hipStream_t stream);
 hipError_t bf_warm_module();
+hipError_t bf_launch_verify_div3(float D, float y, uint32_t *d_mismatches, hipStream_t stream);
 
 #endif

@@ -27,6 +27,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 namespace {
 
 typedef float floatx4 __attribute__((ext_vector_type(4)));
@@ -46,15 +48,37 @@ __device__ __forceinline__ void store_global(T *p, const T v)
 }
 
 // (cos, sin) of one coefficient, fast path (bf_math.h; swept exhaustively).
+//   DIV3   : 3-op divide by the launch constant (only when dcs_bf_create has
+//            verified it exact for this D), else the 5-op form
+//   LOWDEG : low-degree polynomials (only when every |fRotation| of the wave < 500)
+template <bool DIV3, bool LOWDEG>
 __device__ __forceinline__ void coeff_fast(const float fRate, const float fPhase0, const float fChan,
                                            const float D, const float y, float &re, float &im)
 {
-    const float rot = dcs_rotation(fRate, fPhase0, fChan, D, y);
+    const float rot = dcs_rotation<DIV3>(fRate, fPhase0, fChan, D, y);
 #ifdef DCS_USE_OCML_SINCOS // A/B build only (tools/sincos_ab.py): __ocml_sincos_f32
     sincosf(rot, &im, &re);
 #else
-    dcs_sincos_fast(rot, &im, &re);
+    dcs_sincos_fast<LOWDEG>(rot, &im, &re);
 #endif
+}
+
+// Run `body(div3, lowdeg)` with the two compile-time switches chosen from
+// wave-uniform run-time values (the branch sits outside the channel loop).
+template <typename F>
+__device__ __forceinline__ void dispatch_fast(const bool div3, const bool lowdeg, F &&body)
+{
+    if (div3) {
+        if (lowdeg)
+            body(std::true_type{}, std::true_type{});
+        else
+            body(std::true_type{}, std::false_type{});
+    } else {
+        if (lowdeg)
+            body(std::false_type{}, std::true_type{});
+        else
+            body(std::false_type{}, std::false_type{});
+    }
 }
 
 // Slow path: hardware-sequence IEEE divide and fp64 sincos rounded once to
@@ -134,7 +158,7 @@ __global__ void __launch_bounds__(kBlock) bf_tiled_kernel(const bf_tiled_args a)
     const uint32_t p0 = pair_base + li;
 
     float fRate[PPL], fPhase0[PPL];
-    bool fast = true;
+    uint32_t cls = DCS_CLASS_FAST_LOW;
 #pragma unroll
     for (int j = 0; j < PPL; j += 2) {
         const floatx4 v = *reinterpret_cast<const floatx4 *>(&s_terms[2 * (li + j)]);
@@ -144,8 +168,9 @@ __global__ void __launch_bounds__(kBlock) bf_tiled_kernel(const bf_tiled_args a)
         fPhase0[j + 1] = v.w;
     }
 #pragma unroll
-    for (int j = 0; j < PPL; j++) fast = fast && dcs_pair_is_fast(fRate[j], fPhase0[j], a.k.fRotBoundScale);
-    const bool wave_slow = __builtin_amdgcn_ballot_w64(!fast) != 0ull;
+    for (int j = 0; j < PPL; j++) cls = max(cls, dcs_pair_class(fRate[j], fPhase0[j], a.k.fRotBoundScale, a.k.fLowDegLimit));
+    const bool wave_slow = __builtin_amdgcn_ballot_w64(cls == DCS_CLASS_SLOW) != 0ull;
+    const bool wave_low = __builtin_amdgcn_ballot_w64(cls != DCS_CLASS_FAST_LOW) == 0ull;
 
     const uint32_t cbeg = cb * a.chan_per_block;
     const uint32_t cend = min(cbeg + a.chan_per_block, a.nc);
@@ -197,15 +222,18 @@ __global__ void __launch_bounds__(kBlock) bf_tiled_kernel(const bf_tiled_args a)
     }
 
     if (!wave_slow) {
+        dispatch_fast(a.k.uDiv3Exact != 0u, wave_low, [&](auto div3, auto lowdeg) {
 #pragma unroll 2
-        for (uint32_t c = cbeg + row; c < cend; c += ROWS) {
-            const float fChan = (float)(a.c0 + c);
-            float re[PPL], im[PPL];
+            for (uint32_t c = cbeg + row; c < cend; c += ROWS) {
+                const float fChan = (float)(a.c0 + c);
+                float re[PPL], im[PPL];
 #pragma unroll
-            for (int j = 0; j < PPL; j++) coeff_fast(fRate[j], fPhase0[j], fChan, D, y, re[j], im[j]);
-            emit(re, im);
-            dst += step;
-        }
+                for (int j = 0; j < PPL; j++)
+                    coeff_fast<decltype(div3)::value, decltype(lowdeg)::value>(fRate[j], fPhase0[j], fChan, D, y, re[j], im[j]);
+                emit(re, im);
+                dst += step;
+            }
+        });
     } else {
         for (uint32_t c = cbeg + row; c < cend; c += ROWS) {
             const float fChan = (float)(a.c0 + c);
@@ -256,9 +284,9 @@ __global__ void __launch_bounds__(NW * 64) bf_rows_kernel(const bf_rows_args a)
 
     // slow-path flags of this wave's pairs: one dword per 64 pairs (scalar loads)
     const uint32_t *fl = a.flags + (uint64_t)t * (a.pairs_pad / 64u) + chunk * (uint32_t)(TILE / 64);
-    uint32_t slow = 0;
+    uint32_t cls = DCS_CLASS_FAST_LOW; // max class over this wave's pairs
 #pragma unroll
-    for (int j = 0; j < TILE / 64; j++) slow |= fl[j];
+    for (int j = 0; j < TILE / 64; j++) cls = max(cls, fl[j]);
 
     float fRate[PPL], fPhase0[PPL];
     const floatx4 *tp = reinterpret_cast<const floatx4 *>(a.terms + 2u * ((uint64_t)t * a.pairs_pad + p0));
@@ -301,25 +329,27 @@ __global__ void __launch_bounds__(NW * 64) bf_rows_kernel(const bf_rows_args a)
         }
     };
 
-    if (__builtin_expect(slow == 0u, 1)) {
+    if (__builtin_expect(cls != DCS_CLASS_SLOW, 1)) {
+        dispatch_fast(a.div3 != 0u, cls == DCS_CLASS_FAST_LOW, [&](auto div3, auto lowdeg) {
 #pragma unroll
-        for (int r = 0; r < RPW; r++) {
-            if (c + r < a.nc) {
-                const float fChan = (float)(a.c0 + c + r);
-                float re[PPL], im[PPL];
+            for (int r = 0; r < RPW; r++) {
+                if (c + r < a.nc) {
+                    const float fChan = (float)(a.c0 + c + r);
+                    float re[PPL], im[PPL];
 #pragma unroll
-                for (int j = 0; j < PPL; j++) {
-                    if constexpr (NOMATH) {
-                        re[j] = fRate[j];
-                        im[j] = fPhase0[j] + fChan;
-                    } else {
-                        coeff_fast(fRate[j], fPhase0[j], fChan, D, y, re[j], im[j]);
+                    for (int j = 0; j < PPL; j++) {
+                        if constexpr (NOMATH) {
+                            re[j] = fRate[j];
+                            im[j] = fPhase0[j] + fChan;
+                        } else {
+                            coeff_fast<decltype(div3)::value, decltype(lowdeg)::value>(fRate[j], fPhase0[j], fChan, D, y, re[j], im[j]);
+                        }
                     }
+                    emit(re, im);
+                    dst += row_bytes;
                 }
-                emit(re, im);
-                dst += row_bytes;
             }
-        }
+        });
     } else {
         for (int r = 0; r < RPW; r++) {
             if (c + r < a.nc) {
@@ -334,8 +364,8 @@ __global__ void __launch_bounds__(NW * 64) bf_rows_kernel(const bf_rows_args a)
     }
 }
 
-// terms[t][p] = {fRateTerm, fPhase0}; flags[t][p/64] != 0 iff any of those 64
-// pairs must take the slow path.  p runs to pairs_pad (a multiple of 256);
+// terms[t][p] = {fRateTerm, fPhase0}; flags[t][p/64] = the highest dcs_pair_class of
+// those 64 pairs.  p runs to pairs_pad (a multiple of 256);
 // pairs past n_pairs get zeros.  One lane per (t, p); 64 lanes = one flag word.
 __global__ void __launch_bounds__(kBlock) bf_terms_kernel(const bf_terms_args a)
 {
@@ -352,10 +382,13 @@ __global__ void __launch_bounds__(kBlock) bf_terms_kernel(const bf_terms_args a)
         d.fPhaseRate_radps = raw.w;
         dcs_pair_terms(d, dt, a.k.dHalfChannels, a.k.dDenominator, &fRate, &fPhase0);
     }
-    const bool slow = !dcs_pair_is_fast(fRate, fPhase0, a.k.fRotBoundScale);
-    const unsigned long long m = __builtin_amdgcn_ballot_w64(slow);
+    const uint32_t cls = dcs_pair_class(fRate, fPhase0, a.k.fRotBoundScale, a.k.fLowDegLimit);
+    const uint32_t wave_cls = __builtin_amdgcn_ballot_w64(cls == DCS_CLASS_SLOW) != 0ull
+                                  ? DCS_CLASS_SLOW
+                                  : (__builtin_amdgcn_ballot_w64(cls == DCS_CLASS_FAST_HIGH) != 0ull ? DCS_CLASS_FAST_HIGH
+                                                                                                    : DCS_CLASS_FAST_LOW);
     *reinterpret_cast<floatx2 *>(a.terms + 2u * ((uint64_t)t * a.pairs_pad + p)) = floatx2{fRate, fPhase0};
-    if ((threadIdx.x & 63u) == 0u) a.flags[(uint64_t)t * (a.pairs_pad / 64u) + p / 64u] = (m != 0ull) ? 1u : 0u;
+    if ((threadIdx.x & 63u) == 0u) a.flags[(uint64_t)t * (a.pairs_pad / 64u) + p / 64u] = wave_cls;
 }
 
 // ---------------------------------------------------------------------------
@@ -381,7 +414,7 @@ __global__ void __launch_bounds__(kBlock) bf_bform_terms_kernel(const bf_bform_t
 {
     const uint32_t p = blockIdx.x * kBlock + threadIdx.x; // table index b*A + a
     const uint32_t t = blockIdx.y;
-    bool slow = false;
+    uint32_t cls = DCS_CLASS_FAST_LOW;
     if (p < a.n_pairs) {
         const floatx4 raw = *reinterpret_cast<const floatx4 *>(&a.delays[p]);
         dcs_delay_vals d;
@@ -391,12 +424,13 @@ __global__ void __launch_bounds__(kBlock) bf_bform_terms_kernel(const bf_bform_t
         d.fPhaseRate_radps = raw.w;
         float fRate, fPhase0;
         dcs_pair_terms(d, a.dt_dev[t], a.k.dHalfChannels, a.k.dDenominator, &fRate, &fPhase0);
-        slow = !dcs_pair_is_fast(fRate, fPhase0, a.k.fRotBoundScale);
+        cls = dcs_pair_class(fRate, fPhase0, a.k.fRotBoundScale, a.k.fLowDegLimit);
         const uint32_t b = p / a.A, ant = p - b * a.A;
         *reinterpret_cast<floatx2 *>(a.terms + 2u * ((uint64_t)t * a.n_pairs + (uint64_t)ant * a.B + b)) =
             floatx2{fRate, fPhase0};
     }
-    if (__builtin_amdgcn_ballot_w64(slow) != 0ull && (threadIdx.x & 63u) == 0u) atomicOr(&a.flags[t], 1u);
+    // flags[t] = highest class at time t (zeroed by the caller)
+    if (cls != DCS_CLASS_FAST_LOW) atomicMax(&a.flags[t], cls);
 }
 
 __global__ void __launch_bounds__(kBlock) bf_beamform_kernel(const bf_beamform_args a)
@@ -415,7 +449,9 @@ __global__ void __launch_bounds__(kBlock) bf_beamform_kernel(const bf_beamform_a
     const bool live = b < a.B;
 
     // any pair of these 16 time steps outside the fast path's proven range?
-    const int slow = __syncthreads_or((int)a.flags[tex * 16u + (threadIdx.x & 15u)]);
+    const uint32_t fl = a.flags[tex * 16u + (threadIdx.x & 15u)];
+    const int slow = __syncthreads_or((int)(fl == DCS_CLASS_SLOW));
+    const int high = __syncthreads_or((int)(fl != DCS_CLASS_FAST_LOW));
 
     const float D = a.k.fDenominator, y = a.k.fRcpDenominator;
     const float *tp = a.terms + 2u * ((uint64_t)t * a.A * a.B + (live ? b : 0u));
@@ -433,16 +469,18 @@ __global__ void __launch_bounds__(kBlock) bf_beamform_kernel(const bf_beamform_a
         const float fChan = (float)c;
         float acc_re = 0.0f, acc_im = 0.0f;
         if (!slow) {
+            dispatch_fast(a.k.uDiv3Exact != 0u, !high, [&](auto div3, auto lowdeg) {
 #pragma unroll 4
-            for (uint32_t ant = 0; ant < a.A; ant++) {
-                const floatx2 kp = *reinterpret_cast<const floatx2 *>(tp + 2u * (uint64_t)ant * a.B);
-                float re, im;
-                coeff_fast(kp.x, kp.y, fChan, D, y, re, im);
-                const float sre = (float)s_ant[(ant * 16u + t_in) * 2u], sim = (float)s_ant[(ant * 16u + t_in) * 2u + 1u];
-                const float pr = re * sre, pi = im * sim; // product, then sum: two roundings each
-                acc_re = acc_re + pr;
-                acc_im = acc_im + pi;
-            }
+                for (uint32_t ant = 0; ant < a.A; ant++) {
+                    const floatx2 kp = *reinterpret_cast<const floatx2 *>(tp + 2u * (uint64_t)ant * a.B);
+                    float re, im;
+                    coeff_fast<decltype(div3)::value, decltype(lowdeg)::value>(kp.x, kp.y, fChan, D, y, re, im);
+                    const float sre = (float)s_ant[(ant * 16u + t_in) * 2u], sim = (float)s_ant[(ant * 16u + t_in) * 2u + 1u];
+                    const float pr = re * sre, pi = im * sim; // product, then sum: two roundings each
+                    acc_re = acc_re + pr;
+                    acc_im = acc_im + pi;
+                }
+            });
         } else {
             for (uint32_t ant = 0; ant < a.A; ant++) {
                 const floatx2 kp = *reinterpret_cast<const floatx2 *>(tp + 2u * (uint64_t)ant * a.B);
@@ -479,14 +517,16 @@ __global__ void __launch_bounds__(kBlock) bf_naive_kernel(const bf_naive_args a)
     d.fPhaseRate_radps = raw.w;
     float fRate, fPhase0;
     dcs_pair_terms(d, a.dt, a.k.dHalfChannels, a.k.dDenominator, &fRate, &fPhase0);
-    const bool fast = dcs_pair_is_fast(fRate, fPhase0, a.k.fRotBoundScale);
+    const uint32_t cls = dcs_pair_class(fRate, fPhase0, a.k.fRotBoundScale, a.k.fLowDegLimit);
     for (uint32_t c = blockIdx.y; c < a.nc; c += gridDim.y) {
         const float fChan = (float)(a.c0 + c);
         float re, im;
-        if (fast)
-            coeff_fast(fRate, fPhase0, fChan, a.k.fDenominator, a.k.fRcpDenominator, re, im);
-        else
+        if (cls == DCS_CLASS_SLOW)
             coeff_slow(fRate, fPhase0, fChan, a.k.fDenominator, re, im);
+        else if (cls == DCS_CLASS_FAST_LOW)
+            coeff_fast<false, true>(fRate, fPhase0, fChan, a.k.fDenominator, a.k.fRcpDenominator, re, im);
+        else
+            coeff_fast<false, false>(fRate, fPhase0, fChan, a.k.fDenominator, a.k.fRcpDenominator, re, im);
         floatx2 *dst = reinterpret_cast<floatx2 *>(a.out) + ((uint64_t)c * a.n_pairs + p);
         *dst = floatx2{re, im};
     }
@@ -512,7 +552,9 @@ __global__ void __launch_bounds__(kBlock) bf_probe_sincos_kernel(int which, cons
     const float v = x[i];
     float fs, fc;
     if (which == 0) {
-        dcs_sincos_fast(v, &fs, &fc);
+        dcs_sincos_fast<false>(v, &fs, &fc);
+    } else if (which == 3) {
+        dcs_sincos_fast<true>(v, &fs, &fc);
     } else if (which == 1) {
         sincosf(v, &fs, &fc); // __ocml_sincos_f32
     } else {
@@ -803,6 +845,23 @@ hipError_t bf_launch_probe_reduce(const void *in, size_t bytes, unsigned long lo
     const size_t n16 = bytes / 16;
     hipLaunchKernelGGL(bf_probe_reduce_kernel, dim3(BF_PROBE_REDUCE_WAVES / (kBlock / 64)), dim3(kBlock), 0, stream,
                        reinterpret_cast<const uintx4 *>(in), n16, d_part);
+    return hipGetLastError();
+}
+
+// Every fp32 significand x in [1, 2): is dcs_div_const3(x, D) the IEEE quotient?
+// (scale-invariant in x, so one binade settles this D; see bf_math.h)
+__global__ void __launch_bounds__(kBlock) bf_verify_div3_kernel(float D, float y, uint32_t *mismatches)
+{
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x; // < 2^23
+    const float x = dcs_bits_f32(0x3f800000u + i);
+    const float q = dcs_div_const3(x, D, y);
+    const float e = x / D; // correctly rounded (-fhip-fp32-correctly-rounded-divide-sqrt, the default)
+    if (dcs_f32_bits(q) != dcs_f32_bits(e)) atomicAdd(mismatches, 1u);
+}
+
+hipError_t bf_launch_verify_div3(float D, float y, uint32_t *d_mismatches, hipStream_t stream)
+{
+    hipLaunchKernelGGL(bf_verify_div3_kernel, dim3((1u << 23) / kBlock), dim3(kBlock), 0, stream, D, y, d_mismatches);
     return hipGetLastError();
 }
 

@@ -43,6 +43,8 @@ struct dcs_bf_consts {
     float fDenominator;      // SAMPLING_PERIOD * NR_CHANNELS, fp32 product (.cu:322)
     float fRcpDenominator;   // RN(1 / fDenominator), fp32 divide on the host
     float fRotBoundScale;    // >= pi * (NR_CHANNELS-1) / fDenominator, with margin
+    uint32_t uDiv3Exact;     // 1: dcs_div_const3 verified == IEEE divide for THIS fDenominator (bf_capi.hip)
+    float fLowDegLimit;      // 500: |fRotation| bound below which the low-degree polynomials are used (0 = never)
     float fPad;
     double dHalfChannels;    // NR_CHANNELS / 2.0 (.cu:323)
     double dDenominator;     // (double) fDenominator (.cu:323)
@@ -91,14 +93,30 @@ DCS_HD float dcs_div_const(const float x, const float D, const float y)
     return dcs_fmaf(r1, y, q1);
 }
 
+// The first correction step alone: q1 = RN(q0 + r0*y).  For almost every D this is
+// already the correctly rounded quotient for ALL x (Brisebarre, Muller, Raina,
+// "Accelerating correctly rounded floating-point division when the divisor is
+// known in advance", IEEE TC 2004: the exceptions are a few divisors with
+// particular significands).  The sequence is invariant under scaling x by powers
+// of two, so checking the 2^23 significands of one binade against the IEEE
+// divide settles it for a given D: dcs_bf_create does that on the device and
+// sets dcs_bf_consts::uDiv3Exact; kernels use this form only then.
+DCS_HD float dcs_div_const3(const float x, const float D, const float y)
+{
+    const float q0 = x * y;
+    const float r0 = dcs_fmaf(-q0, D, x);
+    return dcs_fmaf(r0, y, q0);
+}
+
 // fRotation for channel c (.cu:322,326): three fp32 roundings for fDelayN
 // (mul, mul, divide) and one add.
+template <bool DIV3 = false>
 DCS_HD float dcs_rotation(const float fRateTerm, const float fPhase0, const float fChannel,
                           const float D, const float y)
 {
     const float m1 = fRateTerm * fChannel;
     const float m2 = m1 * DCS_PI_F;
-    const float fDelayN = dcs_div_const(m2, D, y);
+    const float fDelayN = DIV3 ? dcs_div_const3(m2, D, y) : dcs_div_const(m2, D, y);
     return fDelayN + fPhase0;
 }
 
@@ -123,15 +141,26 @@ DCS_HD bool dcs_rate_in_fast_range(const float fRateTerm)
     return (fRateTerm == 0.0f) || (e >= 127u - 60u && e <= 127u + 60u);
 }
 
-// A pair may take the fast path (dcs_div_const + dcs_sincos_fast) for every
-// channel of the launch iff its rate term is in dcs_div_const's range and
-// |fRotation| is provably below DCS_SINCOS_FAST_LIMIT: |fDelayN| <=
-// |fRateTerm| * pi*(C-1)/D * (1 + 2^-21).  NaN/Inf fail every comparison and
-// take the slow path.
-DCS_HD bool dcs_pair_is_fast(const float fRateTerm, const float fPhase0, const float fRotBoundScale)
+// Class of a pair for a whole launch, from a bound on |fRotation| over its
+// channels: |fDelayN| <= |fRateTerm| * pi*(C-1)/D * (1 + 2^-21) (fRotBoundScale
+// carries a 1e-4 margin).
+//   0: bound < fLowDegLimit (500) -> fast path, low-degree polynomials (proven below 512)
+//   1: bound < 32000 -> fast path, full polynomials (proven below 32768)
+//   2: otherwise, or rate term outside dcs_div_const's range, or NaN/Inf
+//      -> slow path (IEEE divide + fp64 sincos)
+#define DCS_CLASS_FAST_LOW 0u
+#define DCS_CLASS_FAST_HIGH 1u
+#define DCS_CLASS_SLOW 2u
+DCS_HD uint32_t dcs_pair_class(const float fRateTerm, const float fPhase0, const float fRotBoundScale,
+                               const float fLowDegLimit = 500.0f)
 {
     const float bound = __builtin_fabsf(fRateTerm) * fRotBoundScale + __builtin_fabsf(fPhase0);
-    return dcs_rate_in_fast_range(fRateTerm) && (bound < 32000.0f);
+    if (!dcs_rate_in_fast_range(fRateTerm) || !(bound < 32000.0f)) return DCS_CLASS_SLOW;
+    return bound < fLowDegLimit ? DCS_CLASS_FAST_LOW : DCS_CLASS_FAST_HIGH;
+}
+DCS_HD bool dcs_pair_is_fast(const float fRateTerm, const float fPhase0, const float fRotBoundScale)
+{
+    return dcs_pair_class(fRateTerm, fPhase0, fRotBoundScale) != DCS_CLASS_SLOW;
 }
 
 // ---------------------------------------------------------------------------
@@ -168,6 +197,27 @@ DCS_HD bool dcs_pair_is_fast(const float fRateTerm, const float fPhase0, const f
 #define DCS_C3 2.48015876422869041562e-05f
 #define DCS_C4 -2.75573142971552442759e-07f
 
+// Low-degree set (sin to r^7, cos to r^8): within 1 ULP for every fp32 below 512
+// (swept like the full set; first failures appear in [512, 2048)).
+#define DCS_SINCOS_LOW_LIMIT 512.0f
+#define DCS_LS1 -1.66666552424430847168e-01f
+#define DCS_LS2 8.33216123282909393311e-03f
+#define DCS_LS3 -1.95152955711819231510e-04f
+#define DCS_LC1 4.16666455566883087158e-02f
+#define DCS_LC2 -1.38873164542019367218e-03f
+#define DCS_LC3 2.44331567955669015646e-05f
+
+// v ^ (m & 0x80000000): one v_bitop3_b32 on gfx950 (truth table 0x6c over (m, v, mask)).
+DCS_HD uint32_t dcs_xor_sign_of(const uint32_t v, const uint32_t m)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_bitop3_b32(m, v, 0x80000000u, 0x6c);
+#else
+    return v ^ (m & 0x80000000u);
+#endif
+}
+
+template <bool LOWDEG = false>
 DCS_HD void dcs_sincos_fast(const float x, float *fSin, float *fCos)
 {
     const float nb = dcs_fmaf(x, DCS_TWO_OVER_PI, DCS_RINT_MAGIC);
@@ -178,22 +228,32 @@ DCS_HD void dcs_sincos_fast(const float x, float *fSin, float *fCos)
     r = dcs_fmaf(-n, DCS_PIO2_3, r);
     const float s = r * r;
 
-    float ps = dcs_fmaf(s, DCS_S4, DCS_S3);
-    ps = dcs_fmaf(ps, s, DCS_S2);
-    ps = dcs_fmaf(ps, s, DCS_S1);
-    float pc = dcs_fmaf(s, DCS_C4, DCS_C3);
-    pc = dcs_fmaf(pc, s, DCS_C2);
-    pc = dcs_fmaf(pc, s, DCS_C1);
+    float ps, pc;
+    if (LOWDEG) {
+        ps = dcs_fmaf(s, DCS_LS3, DCS_LS2);
+        ps = dcs_fmaf(ps, s, DCS_LS1);
+        pc = dcs_fmaf(s, DCS_LC3, DCS_LC2);
+        pc = dcs_fmaf(pc, s, DCS_LC1);
+    } else {
+        ps = dcs_fmaf(s, DCS_S4, DCS_S3);
+        ps = dcs_fmaf(ps, s, DCS_S2);
+        ps = dcs_fmaf(ps, s, DCS_S1);
+        pc = dcs_fmaf(s, DCS_C4, DCS_C3);
+        pc = dcs_fmaf(pc, s, DCS_C2);
+        pc = dcs_fmaf(pc, s, DCS_C1);
+    }
     pc = dcs_fmaf(pc, s, -0.5f);
     const float sr = dcs_fmaf(s * r, ps, r);
     const float cr = dcs_fmaf(s, pc, 1.0f);
 
     // q mod 4:  0: (cr, sr)  1: (-sr, cr)  2: (-cr, -sr)  3: (sr, -cr)
-    const bool swap = (q & 1u) != 0u;
-    const uint32_t sin_sign = (q << 30) & 0x80000000u;      // bit 1 of q
-    const uint32_t cos_sign = sin_sign ^ (q << 31);         // bit 1 xor bit 0
-    *fSin = dcs_bits_f32(dcs_f32_bits(swap ? cr : sr) ^ sin_sign);
-    *fCos = dcs_bits_f32(dcs_f32_bits(swap ? sr : cr) ^ cos_sign);
+    // sin's sign = bit 1 of q; cos's sign = bit 1 xor bit 0.
+    const uint32_t t30 = q << 30, t31 = q << 31;           // bit 1 / bit 0 moved to the sign position
+    const bool swap = (int32_t)t31 < 0;
+    const uint32_t us = dcs_f32_bits(swap ? cr : sr);
+    const uint32_t uc = dcs_f32_bits(swap ? sr : cr) ^ t31;
+    *fSin = dcs_bits_f32(dcs_xor_sign_of(us, t30));
+    *fCos = dcs_bits_f32(dcs_xor_sign_of(uc, t30));
 }
 
 #endif // DCS_BF_MATH_H

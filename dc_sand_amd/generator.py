@@ -111,11 +111,26 @@ class SteeringCoefficientGenerator:
         )
 
     def set_tuning(self, form: int = 0, nontemporal: int = -1, chan_per_block: int = 0, tiles_per_block: int = 0,
-                   waves_per_block: int = 0, rows_per_wave: int = 0, xcd_remap: int = -1, nomath: bool = False) -> None:
+                   waves_per_block: int = 0, rows_per_wave: int = 0, xcd_remap: int = -1, nomath: bool = False,
+                   math_mode: int = 0) -> None:
         """``struct dcs_bf_tuning``; ``set_tuning()`` restores the defaults."""
-        t = (ctypes.c_int32 * 8)(form, nontemporal, chan_per_block, tiles_per_block, waves_per_block, rows_per_wave,
-                                 xcd_remap, 1 if nomath else 0)
+        t = (ctypes.c_int32 * 9)(form, nontemporal, chan_per_block, tiles_per_block, waves_per_block, rows_per_wave,
+                                 xcd_remap, 1 if nomath else 0, math_mode)
         check(_lib.lib().dcs_bf_set_tuning(c_void_p(self._h), ctypes.cast(t, c_void_p)), "dcs_bf_set_tuning")
+
+    TUNING_FIELDS = ("form", "nontemporal", "chan_per_block", "tiles_per_block", "waves_per_block", "rows_per_wave",
+                     "xcd_remap", "nomath", "math_mode")
+
+    def autotune(self, d_out, out_bytes: int, bitwidth: int = B32, stream=None) -> dict:
+        """``dcs_bf_autotune``: time the tiled form's geometries on this device for this
+        shape, keep the fastest for this context, return the chosen knobs."""
+        t = (ctypes.c_int32 * 9)()
+        check(
+            _lib.lib().dcs_bf_autotune(c_void_p(self._h), int(bitwidth), c_void_p(int(d_out)), int(out_bytes), _s(stream),
+                                       ctypes.cast(t, c_void_p)),
+            "dcs_bf_autotune",
+        )
+        return dict(zip(self.TUNING_FIELDS, (int(v) for v in t)))
 
     def output_bytes(self, bitwidth: int = B32, nt: int = 1) -> int:
         return output_bytes(self.params, bitwidth, nt)

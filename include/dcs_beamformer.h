@@ -195,8 +195,21 @@ struct dcs_bf_tuning {
     int32_t rows_per_wave;   /* form 2: 1, 2, 4 */
     int32_t xcd_remap;       /* form 2: -1 default, 0, 1 */
     int32_t nomath;          /* probe: addressing and stores only */
+    int32_t math_mode;       /* A/B of the arithmetic forms (all give the same bits): bit 0 = keep the 5-op
+                              * divide even where the 3-op form was verified exact for this divisor; bit 1 =
+                              * keep the full-degree polynomials even where the low-degree ones are proven */
 };
 int dcs_bf_set_tuning(dcs_bf_context *ctx, const struct dcs_bf_tuning *t);
+
+/* Measure the tiled form's launch geometries on THIS device for THIS shape (and the
+ * delay table currently set) and keep the fastest: the optimum is sharp and moves with
+ * shape and arithmetic form (profiles/r01_geometry_sweep.md).  Generates channels
+ * [0, min(nr_channels, out_bytes / row)) of time index 1 into d_out repeatedly
+ * (~60 launches); blocks on events, so it cannot be captured in a graph.  The chosen
+ * knobs are written to *chosen (may be NULL) and stay in effect for this context.
+ * Results do not depend on the geometry (every one gives the same bits). */
+int dcs_bf_autotune(dcs_bf_context *ctx, int bitwidth, void *d_out, size_t out_bytes, void *stream,
+                    struct dcs_bf_tuning *chosen);
 
 /* get_time(), BCT.cu:422-454: the real-time utilisation model, from a kernel
  * duration in ms.  out[0] = per single time unit, out[1] = per
@@ -218,7 +231,8 @@ int dcs_bf_stream_end(dcs_bf_stream *s);
 
 /* ---- probes (used by tests / bench to characterise the device) ----------- */
 /* Device evaluation of the two sincos forms on n arguments:
- * which = 0 the library's fast path, 1 __ocml_sincos_f32, 2 the fp64 slow path. */
+ * which = 0 the library's fast path (full polynomials), 1 __ocml_sincos_f32, 2 the fp64
+ * slow path, 3 the fast path with the low-degree polynomials (valid below 512). */
 int dcs_probe_sincos(int which, const float *d_x, size_t n, float *d_sin, float *d_cos, void *stream);
 /* Pure store kernel with the generator's access pattern and no arithmetic: the
  * measured HBM-write ceiling the roofline fraction is read against. */

@@ -41,7 +41,10 @@ static void *sincos_worker(void *arg)
     for (uint32_t u = j->lo; u < j->hi; u++) {
         float x = dcs_bits_f32(u);
         float s, c;
-        dcs_sincos_fast(x, &s, &c);
+        if (j->variant == 1)
+            dcs_sincos_fast<true>(x, &s, &c);
+        else
+            dcs_sincos_fast<false>(x, &s, &c);
         float es = (float)sin((double)x), ec = (float)cos((double)x);
         uint32_t ds = ulp_diff(s, es), dc = ulp_diff(c, ec);
         if (ds > j->max_a) { j->max_a = ds; j->worst_a = u; }
@@ -57,7 +60,7 @@ static void *div_worker(void *arg)
     struct sweep_job *j = (struct sweep_job *)arg;
     for (uint32_t u = j->lo; u < j->hi; u++) {
         float x = dcs_bits_f32(u);
-        float q = dcs_div_const(x, j->D, j->y);
+        float q = j->variant == 1 ? dcs_div_const3(x, j->D, j->y) : dcs_div_const(x, j->D, j->y);
         volatile float xd = x, dd = j->D;
         float e = xd / dd;
         if (dcs_f32_bits(q) != dcs_f32_bits(e)) {
@@ -98,66 +101,89 @@ static void run_sweep(void *(*fn)(void *), struct sweep_job *proto, int nthreads
     free(th);
 }
 
+template <bool DIV3, bool LOW>
+static void coeff_fast_host(float k, float p0, float fc, float D, float y, float *re, float *im)
+{
+    const float rot = dcs_rotation<DIV3>(k, p0, fc, D, y);
+    dcs_sincos_fast<LOW>(rot, im, re);
+}
+
 extern "C" {
 
 /* Sweep every fp32 with bit pattern in [lo_bits, hi_bits) (positive floats:
  * monotone in value).  res = {max_ulp_sin, max_ulp_cos, n_sin_over_1,
  * n_cos_over_1, worst_x_bits_sin, worst_x_bits_cos}. */
-void lab_sincos_sweep(uint32_t lo_bits, uint32_t hi_bits, int nthreads, uint64_t *res)
+void lab_sincos_sweep(int lowdeg, uint32_t lo_bits, uint32_t hi_bits, int nthreads, uint64_t *res)
 {
     struct sweep_job p = {}, o;
     p.lo = lo_bits;
     p.hi = hi_bits;
+    p.variant = lowdeg;
     run_sweep(sincos_worker, &p, nthreads, &o);
     res[0] = o.max_a; res[1] = o.max_b; res[2] = o.over_a; res[3] = o.over_b;
     res[4] = o.worst_a; res[5] = o.worst_b;
 }
 
 /* res = {n_mismatch, max_ulp, first_bad_x_bits, n_signed_zero_diffs} */
-void lab_div_sweep(float D, uint32_t lo_bits, uint32_t hi_bits, int nthreads, uint64_t *res)
+void lab_div_sweep(int three_op, float D, uint32_t lo_bits, uint32_t hi_bits, int nthreads, uint64_t *res)
 {
     struct sweep_job p = {}, o;
     p.lo = lo_bits;
     p.hi = hi_bits;
+    p.variant = three_op;
     p.D = D;
     p.y = 1.0f / D;
     run_sweep(div_worker, &p, nthreads, &o);
     res[0] = o.over_a; res[1] = o.max_a; res[2] = o.worst_a; res[3] = o.over_b;
 }
 
-void lab_sincos(const float *x, size_t n, float *s, float *c)
+void lab_sincos(int lowdeg, const float *x, size_t n, float *s, float *c)
 {
-    for (size_t i = 0; i < n; i++) dcs_sincos_fast(x[i], &s[i], &c[i]);
+    for (size_t i = 0; i < n; i++) {
+        if (lowdeg)
+            dcs_sincos_fast<true>(x[i], &s[i], &c[i]);
+        else
+            dcs_sincos_fast<false>(x[i], &s[i], &c[i]);
+    }
 }
 
-/* The device fast path, end to end, for one time step: out[c][i][2]. */
-void lab_generate_fast(const struct dcs_delay_vals *delays, size_t n_pairs,
+/* The device fast path, end to end, for one time step: out[c][i][2].  mode bit 0:
+ * 3-op divide (as when dcs_bf_create verified it), bit 1: force the full polynomials. */
+void lab_generate_fast(int mode, const struct dcs_delay_vals *delays, size_t n_pairs,
                        int32_t nr_channels, float sampling_period, float fDeltaTime,
-                       size_t c0, size_t nc, float *out, uint64_t *n_slow_pairs)
+                       size_t c0, size_t nc, float *out, uint64_t *n_slow_pairs, uint64_t *n_low_pairs)
 {
     const float D = sampling_period * nr_channels;
     const float y = 1.0f / D;
     const double half = nr_channels / 2.0;
-    uint64_t slow = 0;
+    const float scale = (float)((double)(nr_channels - 1) * 3.14159274101257324219 / (double)D * 1.0001);
+    uint64_t slow = 0, low = 0;
     for (size_t i = 0; i < n_pairs; i++) {
         float k, p0;
         dcs_pair_terms(delays[i], fDeltaTime, half, (double)D, &k, &p0);
-        if (!dcs_rate_in_fast_range(k)) slow++;
+        const uint32_t cls = dcs_pair_class(k, p0, scale, (mode & 2) ? 0.0f : 500.0f);
+        if (cls == DCS_CLASS_SLOW) slow++;
+        if (cls == DCS_CLASS_FAST_LOW) low++;
         for (size_t c = c0; c < c0 + nc; c++) {
-            float rot = dcs_rotation(k, p0, (float)c, D, y);
             float s, co;
-            if (fabsf(rot) < DCS_SINCOS_FAST_LIMIT && dcs_rate_in_fast_range(k)) {
-                dcs_sincos_fast(rot, &s, &co);
-            } else {
-                rot = dcs_rotation_ieee(k, p0, (float)c, D);
+            const float fc = (float)c;
+            if (cls == DCS_CLASS_SLOW) {
+                const float rot = dcs_rotation_ieee(k, p0, fc, D);
                 s = (float)sin((double)rot);
                 co = (float)cos((double)rot);
+            } else if (mode & 1) {
+                if (cls == DCS_CLASS_FAST_LOW) coeff_fast_host<true, true>(k, p0, fc, D, y, &co, &s);
+                else coeff_fast_host<true, false>(k, p0, fc, D, y, &co, &s);
+            } else {
+                if (cls == DCS_CLASS_FAST_LOW) coeff_fast_host<false, true>(k, p0, fc, D, y, &co, &s);
+                else coeff_fast_host<false, false>(k, p0, fc, D, y, &co, &s);
             }
             out[2 * ((c - c0) * n_pairs + i)] = co;
             out[2 * ((c - c0) * n_pairs + i) + 1] = s;
         }
     }
     if (n_slow_pairs) *n_slow_pairs = slow;
+    if (n_low_pairs) *n_low_pairs = low;
 }
 
 } // extern "C"

@@ -287,14 +287,14 @@ def test_sincos_probe_fast_path_matches_host_sweep(gpu, oracle):
     dx, ds, dc = gpu.mem_alloc(4 * n), gpu.mem_alloc(4 * n), gpu.mem_alloc(4 * n)
     gpu.memcpy_htod(dx, x)
     V = ctypes.c_void_p
-    for which, limit in ((0, 1), (2, 1)):
+    for which, limit in ((0, 1), (2, 1), (3, 1)):
         _lib.check(_lib.lib().dcs_probe_sincos(which, V(int(dx)), n, V(int(ds)), V(int(dc)), V(None)), "probe")
         s = np.empty(n, np.float32)
         c = np.empty(n, np.float32)
         gpu.memcpy_dtoh(s, ds)
         gpu.memcpy_dtoh(c, dc)
         # the fast path is only used (and only proven) below DCS_SINCOS_FAST_LIMIT
-        sel = np.abs(x) < 32768.0 if which == 0 else np.ones(n, dtype=bool)
+        sel = np.abs(x) < 32768.0 if which == 0 else (np.abs(x) < 512.0 if which == 3 else np.ones(n, dtype=bool))
         es = np.sin(x.astype(np.float64)).astype(np.float32)
         ec = np.cos(x.astype(np.float64)).astype(np.float32)
         assert oracle.max_ulp(s[sel], es[sel], limit)[1] == 0
@@ -540,3 +540,63 @@ def test_cpp_host_against_c_abi(gpu):
     assert run.stdout.count("CPU took") == 3
     for name in ("Multiple Chans+Timestamps", "Multiple Channels", "Naive Implementation"):
         assert name in run.stdout
+
+
+@pytest.mark.parametrize("form", [1, 2])
+def test_arithmetic_forms_agree_and_class_boundaries(gpu, oracle, form):
+    """The fast path has four arithmetic forms (3-op / 5-op divide x low- / full-degree
+    polynomials), chosen per wave from a bound on |fRotation|; all must give the
+    oracle's bits (<= 1 ULP) and each other's bits.  The table mixes pairs below 500 rad,
+    between 500 and 32000 rad and beyond (slow path), so every class occurs, also
+    inside one wave."""
+    from dc_sand_amd import BeamformerParameters
+
+    bp = BeamformerParameters(NR_CHANNELS=200, NR_STATIONS=3, NR_BEAMS=200)
+    table = rand_table(bp.n_pairs, seed=13)
+    table["fDelayRate_sps"][100:140] = 2.0e-5    # ~630 rad at the top channel: full-degree class
+    table["fDelayRate_sps"][300:310] = -4.0e-4   # ~12600 rad
+    table["fDelayRate_sps"][470] = 1.5e-3        # > 32000 rad: slow path
+    table["fPhase_rad"][520:530] = 499.0         # just below / above the class boundary
+    table["fPhase_rad"][530:540] = 501.0
+    op = oracle.params_from(bp)
+    exp = oracle.generate(op, table, 9, 2)
+    outs = []
+    for mode in (0, 1, 2, 3):
+        got = _gen(gpu, bp, table, 9, 2, tuning=dict(form=form, math_mode=mode))
+        _check(oracle, got, exp)
+        outs.append(got.copy())
+    for o in outs[1:]:
+        # the forms are all within 1 ULP of the oracle; between each other they may
+        # differ by the same 1 ULP only where the polynomial degree differs
+        assert oracle.max_ulp(o, outs[0], 2)[1] == 0
+    assert np.array_equal(outs[0].view(np.uint32), outs[1].view(np.uint32))  # divide form never changes a bit
+    assert np.array_equal(outs[2].view(np.uint32), outs[3].view(np.uint32))
+
+
+def test_autotune_keeps_results(gpu, oracle):
+    """dcs_bf_autotune picks a launch geometry by measurement; whatever it picks, the
+    bits are the oracle's."""
+    from dc_sand_amd import BeamformerParameters
+    from dc_sand_amd.generator import SteeringCoefficientGenerator
+
+    bp = BeamformerParameters(NR_CHANNELS=300, NR_STATIONS=16, NR_BEAMS=40)
+    table = rand_table(bp.n_pairs, seed=55)
+    op = oracle.params_from(bp)
+    for bw in (1, 0):
+        g = SteeringCoefficientGenerator(bp)
+        g.upload_delays(table)
+        nbytes = g.output_bytes(bw, 2)
+        buf = gpu.mem_alloc(nbytes)
+        chosen = g.autotune(buf, nbytes, bitwidth=bw)
+        assert chosen["form"] == 1 and chosen["tiles_per_block"] in (1, 2, 4) and chosen["chan_per_block"] >= 1
+        g.generate(buf, nbytes, t0=5, nt=2, bitwidth=bw)
+        exp = oracle.generate(op, table, 5, 2)
+        if bw == 1:
+            out = np.empty(exp.shape, dtype=np.float32)
+            gpu.memcpy_dtoh(out, buf)
+            _check(oracle, out, exp)
+        else:
+            out = np.empty(exp.shape, dtype=np.float16)
+            gpu.memcpy_dtoh(out, buf)
+            assert np.max(np.abs(out.astype(np.float32) - exp)) < 1e-3
+        g.close()

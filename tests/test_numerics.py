@@ -25,11 +25,11 @@ def lab():
     res = subprocess.run(["make", "-C", str(LAB_DIR)], capture_output=True, text=True)
     assert res.returncode == 0, res.stderr
     L = ctypes.CDLL(str(LAB_DIR / "libnumerics_lab.so"))
-    L.lab_sincos_sweep.argtypes = [ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int, ctypes.POINTER(ctypes.c_uint64)]
-    L.lab_div_sweep.argtypes = [ctypes.c_float, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int, ctypes.POINTER(ctypes.c_uint64)]
-    L.lab_sincos.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p]
-    L.lab_generate_fast.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int32, ctypes.c_float, ctypes.c_float,
-                                    ctypes.c_size_t, ctypes.c_size_t, ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64)]
+    L.lab_sincos_sweep.argtypes = [ctypes.c_int, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int, ctypes.POINTER(ctypes.c_uint64)]
+    L.lab_div_sweep.argtypes = [ctypes.c_int, ctypes.c_float, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int, ctypes.POINTER(ctypes.c_uint64)]
+    L.lab_sincos.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p]
+    L.lab_generate_fast.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int32, ctypes.c_float, ctypes.c_float,
+                                    ctypes.c_size_t, ctypes.c_size_t, ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]
     return L
 
 
@@ -38,9 +38,20 @@ def test_sincos_every_fp32_below_fast_limit(lab):
     (float)sin((double)x) / (float)cos((double)x) -- 4.6e8 arguments.  (Below
     2^-40 the reduction is the identity and sin x = x, cos x = 1 exactly.)"""
     res = (ctypes.c_uint64 * 6)()
-    lab.lab_sincos_sweep(_bits(2.0 ** -40), _bits(32768.0), 8, res)
+    lab.lab_sincos_sweep(0, _bits(2.0 ** -40), _bits(32768.0), 8, res)
     assert res[2] == 0 and res[3] == 0, f"over 1 ULP: sin {res[2]}, cos {res[3]}"
     assert res[0] <= 1 and res[1] <= 1
+
+
+def test_low_degree_sincos_every_fp32_below_512(lab):
+    """The low-degree polynomial set (used when every |fRotation| of a wave is < 500):
+    every positive fp32 in [2^-40, 512) within 1 ULP; and it is NOT valid much beyond
+    (the class boundary matters): some argument in [512, 32768) is 2 ULP off."""
+    res = (ctypes.c_uint64 * 6)()
+    lab.lab_sincos_sweep(1, _bits(2.0 ** -40), _bits(512.0), 8, res)
+    assert res[2] == 0 and res[3] == 0, f"over 1 ULP: sin {res[2]}, cos {res[3]}"
+    lab.lab_sincos_sweep(1, _bits(512.0), _bits(32768.0), 8, res)
+    assert res[2] > 0 or res[3] > 0
 
 
 def test_sincos_symmetry_and_tiny_arguments(lab, oracle):
@@ -53,7 +64,7 @@ def test_sincos_symmetry_and_tiny_arguments(lab, oracle):
     ])
     s = np.empty_like(x)
     c = np.empty_like(x)
-    lab.lab_sincos(x.ctypes.data, x.size, s.ctypes.data, c.ctypes.data)
+    lab.lab_sincos(0, x.ctypes.data, x.size, s.ctypes.data, c.ctypes.data)
     es = np.sin(x.astype(np.float64)).astype(np.float32)
     ec = np.cos(x.astype(np.float64)).astype(np.float32)
     assert oracle.max_ulp(s, es, 1)[1] == 0
@@ -63,7 +74,7 @@ def test_sincos_symmetry_and_tiny_arguments(lab, oracle):
     s2 = np.empty_like(x)
     c2 = np.empty_like(x)
     xm = -x
-    lab.lab_sincos(xm.ctypes.data, x.size, s2.ctypes.data, c2.ctypes.data)
+    lab.lab_sincos(0, xm.ctypes.data, x.size, s2.ctypes.data, c2.ctypes.data)
     nz = x != 0
     assert np.array_equal((-s2[nz]).view(np.uint32), s[nz].view(np.uint32))
     assert np.array_equal(c2.view(np.uint32), c.view(np.uint32))
@@ -75,10 +86,24 @@ def test_divide_by_constant_is_correctly_rounded(lab, C):
     [2^-60, 2^90] (1.26e9 values per D), D = SAMPLING_PERIOD * C."""
     D = np.float32(1e-7) * np.float32(C)
     res = (ctypes.c_uint64 * 4)()
-    lab.lab_div_sweep(D, _bits(2.0 ** -60), _bits(2.0 ** 90), 8, res)
+    lab.lab_div_sweep(0, D, _bits(2.0 ** -60), _bits(2.0 ** 90), 8, res)
     assert res[0] == 0, f"{res[0]} mismatches, max {res[1]} ULP, first x bits {res[2]:#x}"
     # negative arguments
-    lab.lab_div_sweep(D, _bits(-(2.0 ** -10)), _bits(-(2.0 ** 10)), 8, res)
+    lab.lab_div_sweep(0, D, _bits(-(2.0 ** -10)), _bits(-(2.0 ** 10)), 8, res)
+    assert res[0] == 0
+
+
+@pytest.mark.parametrize("C", [1, 3, 64, 1000, 1024, 4096, 12345, 32768, 1 << 24])
+def test_three_op_divide_one_binade_decides(lab, C):
+    """dcs_div_const3: the check dcs_bf_create runs on the device (all 2^23
+    significands of one binade) predicts the whole range -- the sequence is invariant
+    under scaling x by powers of two.  For these divisors both sweeps are clean."""
+    D = np.float32(1e-7) * np.float32(C)
+    res = (ctypes.c_uint64 * 4)()
+    lab.lab_div_sweep(1, D, _bits(1.0), _bits(2.0), 8, res)
+    one_binade = res[0]
+    lab.lab_div_sweep(1, D, _bits(2.0 ** -60), _bits(2.0 ** 90), 8, res)
+    assert (one_binade == 0) == (res[0] == 0)
     assert res[0] == 0
 
 
@@ -96,7 +121,10 @@ def test_emulated_fast_path_vs_oracle(lab, oracle, C, A, B, seeded):
         dt = oracle.delta_time(p, t)
         exp = oracle.generate(p, d, t, 1, c0, nc)
         got = np.empty_like(exp)
-        slow = ctypes.c_uint64()
-        lab.lab_generate_fast(d.ctypes.data, A * B, C, np.float32(1e-7), dt, c0, nc, got.ctypes.data, ctypes.byref(slow))
-        mx, n_over, first = oracle.max_ulp(got, exp, 1)
-        assert n_over == 0 and slow.value == 0, (t, mx, n_over, first)
+        for mode in (0, 1, 2, 3):  # bit 0: 3-op divide, bit 1: full polynomials only
+            slow, low = ctypes.c_uint64(), ctypes.c_uint64()
+            lab.lab_generate_fast(mode, d.ctypes.data, A * B, C, np.float32(1e-7), dt, c0, nc, got.ctypes.data, ctypes.byref(slow),
+                                  ctypes.byref(low))
+            mx, n_over, first = oracle.max_ulp(got, exp, 1)
+            assert n_over == 0 and slow.value == 0, (t, mode, mx, n_over, first)
+            assert (low.value == 0) if (mode & 2) else (low.value == A * B)

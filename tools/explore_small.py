@@ -19,16 +19,22 @@ def main():
     buf = device.mem_alloc(gen.output_bytes(1, 1))
     res = []
 
+    import os
+    math_mode = int(os.environ.get("DCS_MATH_MODE", "0"))
+    only = os.environ.get("DCS_ONLY", "")
+
     def run(label, bitwidth, **tuning):
+        if only and not label.startswith(only):
+            return
         nbytes = gen.output_bytes(bitwidth, 1)
-        gen.set_tuning(**tuning)
+        gen.set_tuning(math_mode=math_mode, **tuning)
         med, mn = timeit(lambda: gen.generate(buf, nbytes, t0=1, nt=1, bitwidth=bitwidth), warm=2, reps=9)
         res.append((ncoeff / med / 1e6, label))
         print(f"{label}: med {med:.3f} ms min {mn:.3f} -> {ncoeff / med / 1e6:.1f} Gcoeff/s {nbytes / med / 1e9:.2f} TB/s", flush=True)
 
     for bw, name in ((1, "fp32"), (0, "fp16")):
         for tpb in (1, 2, 4):
-            for cpb in (4, 8, 12, 16, 24, 32):
+            for cpb in (4, 8, 12, 16, 20, 24, 32):
                 for nts in (0, 1):
                     run(f"{name} tiled tpb={tpb} cpb={cpb:3d} nt={nts}", bw, form=1, tiles_per_block=tpb, chan_per_block=cpb, nontemporal=nts)
         for nw in (4, 8, 16):
