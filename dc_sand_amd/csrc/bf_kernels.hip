@@ -433,9 +433,12 @@ __global__ void __launch_bounds__(kBlock) bf_bform_terms_kernel(const bf_bform_t
     if (cls != DCS_CLASS_FAST_LOW) atomicMax(&a.flags[t], cls);
 }
 
+// CH channels per pass: a lane's terms load and the LDS sample reads are shared by CH
+// independent coefficient chains (more ILP, fewer loads per product).
+template <int CH>
 __global__ void __launch_bounds__(kBlock) bf_beamform_kernel(const bf_beamform_args a)
 {
-    extern __shared__ __attribute__((aligned(16))) int8_t s_ant[]; // [A][16][2]
+    extern __shared__ __attribute__((aligned(16))) int8_t s_ant[]; // [CH][A][16][2]
 
     const uint32_t bid = blockIdx.x;
     const uint32_t bg = bid % a.n_bgroups;
@@ -448,7 +451,7 @@ __global__ void __launch_bounds__(kBlock) bf_beamform_kernel(const bf_beamform_a
     const uint32_t t = tex * 16u + t_in; // time index within this launch's terms table
     const bool live = b < a.B;
 
-    // any pair of these 16 time steps outside the fast path's proven range?
+    // highest pair class over these 16 time steps (bf_bform_terms_kernel)
     const uint32_t fl = a.flags[tex * 16u + (threadIdx.x & 15u)];
     const int slow = __syncthreads_or((int)(fl == DCS_CLASS_SLOW));
     const int high = __syncthreads_or((int)(fl != DCS_CLASS_FAST_LOW));
@@ -460,42 +463,68 @@ __global__ void __launch_bounds__(kBlock) bf_beamform_kernel(const bf_beamform_a
     const uint32_t tex_g = a.tex0 + tex; // 16-sample block within the whole tensor
     const uint32_t words = a.A * 8u;     // dwords of one [A][16][2] int8 block
 
-    for (uint32_t c = cbeg; c < cend; c++) {
-        __syncthreads(); // previous channel's readers are done
-        const uint32_t *src = reinterpret_cast<const uint32_t *>(a.ant) + ((uint64_t)c * a.nt16_total + tex_g) * words;
-        for (uint32_t i = threadIdx.x; i < words; i += kBlock) reinterpret_cast<uint32_t *>(s_ant)[i] = src[i];
+    for (uint32_t c = cbeg; c < cend; c += CH) {
+        __syncthreads(); // previous pass's readers are done
+#pragma unroll
+        for (int h = 0; h < CH; h++) {
+            if (c + h < cend) {
+                const uint32_t *src = reinterpret_cast<const uint32_t *>(a.ant) + ((uint64_t)(c + h) * a.nt16_total + tex_g) * words;
+                for (uint32_t i = threadIdx.x; i < words; i += kBlock) reinterpret_cast<uint32_t *>(s_ant)[h * words + i] = src[i];
+            }
+        }
         __syncthreads();
 
-        const float fChan = (float)c;
-        float acc_re = 0.0f, acc_im = 0.0f;
+        float fChan[CH], acc_re[CH], acc_im[CH];
+#pragma unroll
+        for (int h = 0; h < CH; h++) {
+            fChan[h] = (float)(c + h);
+            acc_re[h] = 0.0f;
+            acc_im[h] = 0.0f;
+        }
+        auto sample = [&](int h, uint32_t ant, float &sre, float &sim) {
+            const int8_t *sp = s_ant + ((size_t)h * a.A + ant) * 32u + t_in * 2u;
+            sre = (float)sp[0];
+            sim = (float)sp[1];
+        };
         if (!slow) {
             dispatch_fast(a.k.uDiv3Exact != 0u, !high, [&](auto div3, auto lowdeg) {
-#pragma unroll 4
+#pragma unroll 2
                 for (uint32_t ant = 0; ant < a.A; ant++) {
                     const floatx2 kp = *reinterpret_cast<const floatx2 *>(tp + 2u * (uint64_t)ant * a.B);
-                    float re, im;
-                    coeff_fast<decltype(div3)::value, decltype(lowdeg)::value>(kp.x, kp.y, fChan, D, y, re, im);
-                    const float sre = (float)s_ant[(ant * 16u + t_in) * 2u], sim = (float)s_ant[(ant * 16u + t_in) * 2u + 1u];
-                    const float pr = re * sre, pi = im * sim; // product, then sum: two roundings each
-                    acc_re = acc_re + pr;
-                    acc_im = acc_im + pi;
+#pragma unroll
+                    for (int h = 0; h < CH; h++) {
+                        float re, im, sre, sim;
+                        coeff_fast<decltype(div3)::value, decltype(lowdeg)::value>(kp.x, kp.y, fChan[h], D, y, re, im);
+                        sample(h, ant, sre, sim);
+                        const float pr = re * sre, pi = im * sim; // product, then sum: two roundings each
+                        acc_re[h] = acc_re[h] + pr;
+                        acc_im[h] = acc_im[h] + pi;
+                    }
                 }
             });
         } else {
             for (uint32_t ant = 0; ant < a.A; ant++) {
                 const floatx2 kp = *reinterpret_cast<const floatx2 *>(tp + 2u * (uint64_t)ant * a.B);
-                float re, im;
-                coeff_slow(kp.x, kp.y, fChan, D, re, im);
-                const float sre = (float)s_ant[(ant * 16u + t_in) * 2u], sim = (float)s_ant[(ant * 16u + t_in) * 2u + 1u];
-                const float pr = re * sre, pi = im * sim;
-                acc_re = acc_re + pr;
-                acc_im = acc_im + pi;
+#pragma unroll 1
+                for (int h = 0; h < CH; h++) {
+                    float re, im, sre, sim;
+                    coeff_slow(kp.x, kp.y, fChan[h], D, re, im);
+                    sample(h, ant, sre, sim);
+                    const float pr = re * sre, pi = im * sim;
+                    acc_re[h] = acc_re[h] + pr;
+                    acc_im[h] = acc_im[h] + pi;
+                }
             }
         }
         if (live) {
-            floatx2 *dst = reinterpret_cast<floatx2 *>(a.beams) +
-                           (((uint64_t)c * a.nt16_total + tex_g) * a.B + b) * 16u + t_in;
-            *dst = floatx2{acc_re, acc_im};
+#pragma unroll
+            for (int h = 0; h < CH; h++) {
+                if (c + h < cend) {
+                    floatx2 *dst = reinterpret_cast<floatx2 *>(a.beams) +
+                                   (((uint64_t)(c + h) * a.nt16_total + tex_g) * a.B + b) * 16u + t_in;
+                    *dst = floatx2{acc_re[h], acc_im[h]};
+                }
+            }
         }
     }
 }
@@ -890,8 +919,13 @@ hipError_t bf_launch_beamform(const bf_beamform_args &a_in, hipStream_t stream)
     a.n_bgroups = (a.B + 15u) / 16u;
     a.n_cblocks = (a.C + a.chan_per_block - 1) / a.chan_per_block;
     const uint64_t blocks = (uint64_t)a.n_bgroups * a.n_cblocks * a.nt16;
-    const size_t lds = (size_t)a.A * 32u;
+    // two channels per pass (CH = 4 measured no better: profiles/r01_fused.md)
+    const int ch = (a.chan_per_block >= 2 && a.A <= 1024u) ? 2 : 1;
+    const size_t lds = (size_t)a.A * 32u * (size_t)ch;
     if (blocks > 0x7fffffffull || lds > 64u * 1024u) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(bf_beamform_kernel, dim3((uint32_t)blocks), dim3(kBlock), lds, stream, a);
+    if (ch == 2)
+        hipLaunchKernelGGL(bf_beamform_kernel<2>, dim3((uint32_t)blocks), dim3(kBlock), lds, stream, a);
+    else
+        hipLaunchKernelGGL(bf_beamform_kernel<1>, dim3((uint32_t)blocks), dim3(kBlock), lds, stream, a);
     return hipGetLastError();
 }
