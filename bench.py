@@ -46,7 +46,10 @@ def parse():
     ap.add_argument("--beams-per-gpu", type=int, default=BEAMS_PER_GPU)
     ap.add_argument("--chan", type=int, default=CHAN)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-autotune", action="store_true", help="keep the library's default launch geometry")
+    ap.add_argument("--no-autotune", action="store_true",
+                    help="keep the library's default launch geometry instead of letting dcs_bf_autotune measure it in the "
+                         "untimed set-up (its trial launches run under separate kernel symbols, template TAG = 1, so a "
+                         "rocprofv3 --stats of this command still averages only the production launches)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline sample time")
     # rehearsal of the N > 1 control flow on a box with fewer GPUs than ranks (never a result):
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="nccl = RCCL over xGMI (the product path)")

@@ -86,6 +86,7 @@ struct dcs_bf_context {
     uint32_t n_pairs;
     int device;
     uint32_t div3_verified; // what verify_div3 found for this context's divisor
+    bool tuning_now;        // inside dcs_bf_autotune: launch the tuner-tagged kernel symbols
     dcs_delay_vals *d_table[2]; // double-buffered compact table
     int cur;                    // buffer generate reads
     bool table_set;
@@ -442,7 +443,7 @@ int prepare_tiled(dcs_bf_context *c, bool out16, const float *dt_dev, float dt0,
     bool ntstore;
     pick_geometry(c, out16, nc, nt, &tpb, &cpb, &ntstore);
     a.chan_per_block = cpb;
-    return (int)bf_prepare_tiled(a, out16, tpb | (c->tune.nomath ? 0x100 : 0), ntstore, l);
+    return (int)bf_prepare_tiled(a, out16, tpb | (c->tune.nomath ? 0x100 : 0) | (c->tuning_now ? 0x200 : 0), ntstore, l);
 }
 
 int launch_tiled(dcs_bf_context *c, bool out16, const float *dt_dev, float dt0, uint32_t nt, uint32_t c0,
@@ -683,6 +684,7 @@ int dcs_bf_autotune(dcs_bf_context *c, int bitwidth, void *d_out, size_t out_byt
     for (int i = 0; i < ncand; i++) cands[i] = {tab[i][0], tab[i][1], 1e30};
 
     const dcs_bf_tuning saved = c->tune;
+    c->tuning_now = true;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     int st = (int)hipEventCreate(&e0);
     if (st == 0) st = (int)hipEventCreate(&e1);
@@ -708,6 +710,7 @@ int dcs_bf_autotune(dcs_bf_context *c, int bitwidth, void *d_out, size_t out_byt
     if (e0) (void)hipEventDestroy(e0);
     if (e1) (void)hipEventDestroy(e1);
     c->tune = saved;
+    c->tuning_now = false;
     if (st != 0) return st;
     int best = 0;
     for (int i = 1; i < ncand; i++)

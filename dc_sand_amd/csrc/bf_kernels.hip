@@ -111,8 +111,11 @@ __device__ __forceinline__ uint32_t pack_half2(const float re, const float im)
 //   NT      : nontemporal stores
 //   ALIGNED : n_pairs % PPL == 0 -> 16-byte stores; otherwise per-pair stores
 //   NOMATH  : addressing/stores only (probe: the store ceiling of this shape)
+//   TAG     : 0 production; 1 = the same code under another symbol, launched only by
+//             dcs_bf_autotune, so that a profiler's per-kernel statistics of the
+//             production launches are not mixed with the tuner's trial geometries
 // ---------------------------------------------------------------------------
-template <bool OUT16, int TPB, bool NT, bool ALIGNED, bool NOMATH>
+template <bool OUT16, int TPB, bool NT, bool ALIGNED, bool NOMATH, int TAG = 0>
 __global__ void __launch_bounds__(kBlock) bf_tiled_kernel(const bf_tiled_args a)
 {
     constexpr int PPL = OUT16 ? 4 : 2;
@@ -672,26 +675,27 @@ __global__ void __launch_bounds__(kBlock) bf_probe_reduce_kernel(const uintx4 *i
 }
 
 template <bool OUT16, int TPB, bool NT, bool ALIGNED>
-const void *tiled_fn_nm(bool nomath)
+const void *tiled_fn_nm(bool nomath, bool tuner)
 {
+    if (tuner) return reinterpret_cast<const void *>(&bf_tiled_kernel<OUT16, TPB, NT, ALIGNED, false, 1>);
     return nomath ? reinterpret_cast<const void *>(&bf_tiled_kernel<OUT16, TPB, NT, ALIGNED, true>)
                   : reinterpret_cast<const void *>(&bf_tiled_kernel<OUT16, TPB, NT, ALIGNED, false>);
 }
 
 template <bool OUT16, int TPB>
-const void *tiled_fn_t(bool nt, bool aligned, bool nomath)
+const void *tiled_fn_t(bool nt, bool aligned, bool nomath, bool tuner)
 {
-    if (nt) return aligned ? tiled_fn_nm<OUT16, TPB, true, true>(nomath) : tiled_fn_nm<OUT16, TPB, true, false>(nomath);
-    return aligned ? tiled_fn_nm<OUT16, TPB, false, true>(nomath) : tiled_fn_nm<OUT16, TPB, false, false>(nomath);
+    if (nt) return aligned ? tiled_fn_nm<OUT16, TPB, true, true>(nomath, tuner) : tiled_fn_nm<OUT16, TPB, true, false>(nomath, tuner);
+    return aligned ? tiled_fn_nm<OUT16, TPB, false, true>(nomath, tuner) : tiled_fn_nm<OUT16, TPB, false, false>(nomath, tuner);
 }
 
 template <bool OUT16>
-const void *tiled_fn_o(int tpb, bool nt, bool aligned, bool nomath)
+const void *tiled_fn_o(int tpb, bool nt, bool aligned, bool nomath, bool tuner)
 {
     switch (tpb) {
-    case 1: return tiled_fn_t<OUT16, 1>(nt, aligned, nomath);
-    case 2: return tiled_fn_t<OUT16, 2>(nt, aligned, nomath);
-    case 4: return tiled_fn_t<OUT16, 4>(nt, aligned, nomath);
+    case 1: return tiled_fn_t<OUT16, 1>(nt, aligned, nomath, tuner);
+    case 2: return tiled_fn_t<OUT16, 2>(nt, aligned, nomath, tuner);
+    case 4: return tiled_fn_t<OUT16, 4>(nt, aligned, nomath, tuner);
     default: return nullptr;
     }
 }
@@ -706,6 +710,7 @@ hipError_t bf_prepare_tiled(const bf_tiled_args &a_in, bool out16, int tiles_per
     if (a.n_pairs == 0 || a.nc == 0 || a.nt == 0) return hipSuccess; // nothing to launch
     if (a.chan_per_block == 0) return hipErrorInvalidValue;
     const bool nomath = (tiles_per_block & 0x100) != 0; // probe flag, see bf_capi.hip
+    const bool tuner = (tiles_per_block & 0x200) != 0;  // dcs_bf_autotune's trial launches
     tiles_per_block &= 0xff;
     const uint32_t ppl = out16 ? 4u : 2u;
     const uint32_t pairs_per_block = 64u * ppl * (uint32_t)tiles_per_block;
@@ -715,8 +720,8 @@ hipError_t bf_prepare_tiled(const bf_tiled_args &a_in, bool out16, int tiles_per
     if (blocks == 0 || blocks > 0x7fffffffull) return hipErrorInvalidValue;
     if (a.dt_dev == nullptr && a.nt != 1) return hipErrorInvalidValue;
     const bool aligned = (a.n_pairs % ppl) == 0 && (reinterpret_cast<uintptr_t>(a.out) % 16u) == 0;
-    const void *fn = out16 ? tiled_fn_o<true>(tiles_per_block, nontemporal, aligned, nomath)
-                           : tiled_fn_o<false>(tiles_per_block, nontemporal, aligned, nomath);
+    const void *fn = out16 ? tiled_fn_o<true>(tiles_per_block, nontemporal, aligned, nomath, tuner)
+                           : tiled_fn_o<false>(tiles_per_block, nontemporal, aligned, nomath, tuner);
     if (!fn) return hipErrorInvalidValue;
     out->func = fn;
     out->grid = dim3((uint32_t)blocks);
