@@ -443,6 +443,7 @@ int prepare_tiled(dcs_bf_context *c, bool out16, const float *dt_dev, float dt0,
     bool ntstore;
     pick_geometry(c, out16, nc, nt, &tpb, &cpb, &ntstore);
     a.chan_per_block = cpb;
+    a.xcd_remap = c->tune.xcd_remap > 0 ? 1u : 0u;
     return (int)bf_prepare_tiled(a, out16, tpb | (c->tune.nomath ? 0x100 : 0) | (c->tuning_now ? 0x200 : 0), ntstore, l);
 }
 
@@ -674,8 +675,8 @@ int dcs_bf_autotune(dcs_bf_context *c, int bitwidth, void *d_out, size_t out_byt
     hipStream_t s = as_stream(stream);
 
     struct cand { int tpb, cpb; double best_ms; };
-    static const int k32[][2] = {{1, 8}, {1, 10}, {1, 12}, {1, 13}, {1, 14}, {1, 15}, {1, 16}, {1, 18}, {1, 20}, {1, 24},
-                                 {1, 32}, {2, 8}, {2, 12}, {2, 16}, {4, 4}, {4, 8}, {4, 16}};
+    static const int k32[][2] = {{1, 8}, {1, 10}, {1, 11}, {1, 12}, {1, 13}, {1, 14}, {1, 15}, {1, 16}, {1, 17}, {1, 18},
+                                 {1, 20}, {1, 24}, {1, 32}, {2, 8}, {2, 12}, {2, 16}, {4, 4}, {4, 8}, {4, 16}};
     static const int k16[][2] = {{1, 32}, {1, 64}, {1, 96}, {1, 128}, {1, 192}, {1, 256}, {2, 32}, {2, 64},
                                  {4, 16}, {4, 32}, {4, 40}, {4, 48}, {4, 64}};
     const int(*tab)[2] = out16 ? k16 : k32;

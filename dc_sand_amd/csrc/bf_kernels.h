@@ -21,6 +21,7 @@ struct bf_tiled_args {
     uint32_t chan_per_block;      // channels a workgroup walks
     uint32_t n_tile_groups;       // ceil(n_pairs / pairs per workgroup)
     uint32_t n_cblocks;           // ceil(nc / chan_per_block)
+    uint32_t xcd_remap;           // workgroups sharing blockIdx % 8 (one XCD) take consecutive (tile, channel block)s
     dcs_bf_consts k;
 };
 

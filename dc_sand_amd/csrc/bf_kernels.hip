@@ -127,7 +127,8 @@ __global__ void __launch_bounds__(kBlock) bf_tiled_kernel(const bf_tiled_args a)
 
     // workgroup -> (tile group, channel block, time step); tile group fastest so
     // that concurrently resident workgroups cover one channel row end to end.
-    const uint32_t bid = blockIdx.x;
+    uint32_t bid = blockIdx.x;
+    if (a.xcd_remap) bid = (bid % 8u) * (gridDim.x / 8u) + bid / 8u; // gridDim.x % 8 == 0 (host)
     const uint32_t tg = bid % a.n_tile_groups;
     const uint32_t rest = bid / a.n_tile_groups;
     const uint32_t cb = rest % a.n_cblocks;
@@ -719,6 +720,7 @@ hipError_t bf_prepare_tiled(const bf_tiled_args &a_in, bool out16, int tiles_per
     const uint64_t blocks = (uint64_t)a.n_tile_groups * a.n_cblocks * a.nt;
     if (blocks == 0 || blocks > 0x7fffffffull) return hipErrorInvalidValue;
     if (a.dt_dev == nullptr && a.nt != 1) return hipErrorInvalidValue;
+    if (blocks % 8u) a.xcd_remap = 0; // the renumbering is a bijection only then
     const bool aligned = (a.n_pairs % ppl) == 0 && (reinterpret_cast<uintptr_t>(a.out) % 16u) == 0;
     const void *fn = out16 ? tiled_fn_o<true>(tiles_per_block, nontemporal, aligned, nomath, tuner)
                            : tiled_fn_o<false>(tiles_per_block, nontemporal, aligned, nomath, tuner);

@@ -101,6 +101,7 @@ TUNINGS = [
     dict(form=1, tiles_per_block=4, chan_per_block=8, nontemporal=1),
     dict(form=1, tiles_per_block=1, chan_per_block=3),
     dict(form=1, tiles_per_block=4, chan_per_block=1000),
+    dict(form=1, tiles_per_block=1, chan_per_block=13, xcd_remap=1),
     dict(form=2, waves_per_block=4, rows_per_wave=1),
     dict(form=2, waves_per_block=4, rows_per_wave=2, nontemporal=1),
     dict(form=2, waves_per_block=8, rows_per_wave=4, xcd_remap=1),
