@@ -308,6 +308,8 @@ int dcs_bf_create(const dcs_bf_params *p, dcs_bf_context **out)
         c->terms_steps = (uint32_t)steps;
     }
     c->tune.nontemporal = -1;
+    c->tune.xcd_remap = -1;
+    c->tune.rows_same_tile = -1;
     int st = DCS_OK;
     do {
         if ((st = (int)hipGetDevice(&c->device)) != 0) break;
@@ -384,6 +386,8 @@ int dcs_bf_set_tuning(dcs_bf_context *c, const dcs_bf_tuning *t)
     if (!t) { // back to the defaults
         std::memset(&c->tune, 0, sizeof(c->tune));
         c->tune.nontemporal = -1;
+        c->tune.xcd_remap = -1;
+        c->tune.rows_same_tile = -1;
         c->k.uDiv3Exact = c->div3_verified;
         c->k.fLowDegLimit = 500.0f;
         return DCS_OK;
@@ -395,8 +399,8 @@ int dcs_bf_set_tuning(dcs_bf_context *c, const dcs_bf_tuning *t)
         return DCS_ERR_INVALID_ARGUMENT;
     if (t->waves_per_block != 0 && t->waves_per_block != 4 && t->waves_per_block != 8 && t->waves_per_block != 16)
         return DCS_ERR_INVALID_ARGUMENT;
-    if (t->rows_per_wave != 0 && t->rows_per_wave != 1 && t->rows_per_wave != 2 && t->rows_per_wave != 4)
-        return DCS_ERR_INVALID_ARGUMENT;
+    if (t->rows_per_wave < 0 || t->rows_per_wave > 4) return DCS_ERR_INVALID_ARGUMENT;
+    if (t->rows_same_tile < -1 || t->rows_same_tile > 1) return DCS_ERR_INVALID_ARGUMENT;
     if (t->xcd_remap < -1 || t->xcd_remap > 1) return DCS_ERR_INVALID_ARGUMENT;
     if (t->math_mode < 0 || t->math_mode > 3) return DCS_ERR_INVALID_ARGUMENT;
     c->tune = *t;
@@ -488,10 +492,13 @@ int launch_rows(dcs_bf_context *c, bool out16, const float *dt_dev, float dt0, u
     a.D = c->k.fDenominator;
     a.y = c->k.fRcpDenominator;
     a.div3 = c->k.uDiv3Exact;
-    const int nw = c->tune.waves_per_block ? c->tune.waves_per_block : 4;
+    // defaults (profiles/r01_geometry_sweep.md): 8 waves share one tile and interleave 16 rows
+    const bool same_tile = c->tune.rows_same_tile < 0 ? true : c->tune.rows_same_tile != 0;
+    const int nw = c->tune.waves_per_block ? c->tune.waves_per_block : (same_tile ? 8 : 4);
     const int rpw = c->tune.rows_per_wave ? c->tune.rows_per_wave : (out16 ? 4 : 2);
     const bool ntstore = c->tune.nontemporal < 0 ? true : c->tune.nontemporal != 0;
-    const bool xcd = c->tune.xcd_remap < 0 ? true : c->tune.xcd_remap != 0;
+    const bool xcd = c->tune.xcd_remap < 0 ? !same_tile : c->tune.xcd_remap != 0;
+    a.same_tile = same_tile ? 1u : 0u;
     return (int)bf_launch_rows(a, out16, nw, rpw, ntstore, xcd, c->tune.nomath != 0, stream);
 }
 

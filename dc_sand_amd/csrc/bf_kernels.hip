@@ -278,11 +278,13 @@ __global__ void __launch_bounds__(NW * 64) bf_rows_kernel(const bf_rows_args a)
     const uint32_t cg = b % a.n_colgroups;
     const uint32_t rg = b / a.n_colgroups;
     const uint32_t t = rg / a.n_rowgroups;
-    const uint32_t c = (rg - t * a.n_rowgroups) * (uint32_t)RPW; // channel within the slab
-
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t chunk = cg * (uint32_t)NW + wave;
+    // same_tile == 0: the NW waves take NW adjacent tiles of RPW consecutive rows;
+    // same_tile == 1: they share ONE tile and interleave NW*RPW rows (wave w: rows w, w+NW, ...)
+    const uint32_t row_step = a.same_tile ? (uint32_t)NW : 1u;
+    const uint32_t c = (rg - t * a.n_rowgroups) * (uint32_t)RPW * row_step + (a.same_tile ? wave : 0u); // channel within the slab
+    const uint32_t chunk = a.same_tile ? cg : cg * (uint32_t)NW + wave;
     if (chunk * (uint32_t)TILE >= a.n_pairs) return; // wave-uniform
     const uint32_t p0 = chunk * (uint32_t)TILE + lane * PPL;
 
@@ -337,8 +339,8 @@ __global__ void __launch_bounds__(NW * 64) bf_rows_kernel(const bf_rows_args a)
         dispatch_fast(a.div3 != 0u, cls == DCS_CLASS_FAST_LOW, [&](auto div3, auto lowdeg) {
 #pragma unroll
             for (int r = 0; r < RPW; r++) {
-                if (c + r < a.nc) {
-                    const float fChan = (float)(a.c0 + c + r);
+                if (c + r * row_step < a.nc) {
+                    const float fChan = (float)(a.c0 + c + r * row_step);
                     float re[PPL], im[PPL];
 #pragma unroll
                     for (int j = 0; j < PPL; j++) {
@@ -350,19 +352,19 @@ __global__ void __launch_bounds__(NW * 64) bf_rows_kernel(const bf_rows_args a)
                         }
                     }
                     emit(re, im);
-                    dst += row_bytes;
+                    dst += row_bytes * row_step;
                 }
             }
         });
     } else {
         for (int r = 0; r < RPW; r++) {
-            if (c + r < a.nc) {
-                const float fChan = (float)(a.c0 + c + r);
+            if (c + r * row_step < a.nc) {
+                const float fChan = (float)(a.c0 + c + r * row_step);
                 float re[PPL], im[PPL];
 #pragma unroll 1
                 for (int j = 0; j < PPL; j++) coeff_slow(fRate[j], fPhase0[j], fChan, D, re[j], im[j]);
                 emit(re, im);
-                dst += row_bytes;
+                dst += row_bytes * row_step;
             }
         }
     }
@@ -828,6 +830,7 @@ hipError_t launch_rows_w(const bf_rows_args &a, int rpw, bool nt, bool aligned, 
     switch (rpw) {
     case 1: return launch_rows_t<OUT16, NW, 1>(a, nt, aligned, nomath, grid, stream);
     case 2: return launch_rows_t<OUT16, NW, 2>(a, nt, aligned, nomath, grid, stream);
+    case 3: return launch_rows_t<OUT16, NW, 3>(a, nt, aligned, nomath, grid, stream);
     case 4: return launch_rows_t<OUT16, NW, 4>(a, nt, aligned, nomath, grid, stream);
     default: return hipErrorInvalidValue;
     }
@@ -863,9 +866,10 @@ hipError_t bf_launch_rows(const bf_rows_args &a_in, bool out16, int waves_per_bl
     bf_rows_args a = a_in;
     if (a.n_pairs == 0 || a.nc == 0 || a.nt == 0) return hipSuccess;
     const uint32_t ppl = out16 ? 4u : 2u;
-    const uint32_t cols = 64u * ppl * (uint32_t)waves_per_block;
+    const uint32_t cols = 64u * ppl * (a.same_tile ? 1u : (uint32_t)waves_per_block);
+    const uint32_t rows = (uint32_t)rows_per_wave * (a.same_tile ? (uint32_t)waves_per_block : 1u);
     a.n_colgroups = (a.n_pairs + cols - 1) / cols;
-    a.n_rowgroups = (a.nc + (uint32_t)rows_per_wave - 1) / (uint32_t)rows_per_wave;
+    a.n_rowgroups = (a.nc + rows - 1) / rows;
     const uint64_t blocks = (uint64_t)a.n_colgroups * a.n_rowgroups * a.nt;
     if (blocks == 0 || blocks > 0x7fffffffull) return hipErrorInvalidValue;
     a.xcd_remap = (xcd_remap && (blocks % 8u) == 0u) ? 1u : 0u;

@@ -192,9 +192,11 @@ struct dcs_bf_tuning {
     int32_t chan_per_block;  /* form 1 */
     int32_t tiles_per_block; /* form 1: 1, 2, 4 */
     int32_t waves_per_block; /* form 2: 4, 8, 16 */
-    int32_t rows_per_wave;   /* form 2: 1, 2, 4 */
-    int32_t xcd_remap;       /* form 2: -1 default, 0, 1 */
+    int32_t rows_per_wave;   /* form 2: 1..4 */
+    int32_t xcd_remap;       /* -1 default, 0, 1: workgroups sharing blockIdx % 8 (one XCD) take consecutive work */
     int32_t nomath;          /* probe: addressing and stores only */
+    int32_t rows_same_tile;  /* form 2: -1 default, 0 = the waves take adjacent tiles, 1 = they share one tile and
+                              * interleave rows */
     int32_t math_mode;       /* A/B of the arithmetic forms (all give the same bits): bit 0 = keep the 5-op
                               * divide even where the 3-op form was verified exact for this divisor; bit 1 =
                               * keep the full-degree polynomials even where the low-degree ones are proven */
