@@ -604,3 +604,17 @@ def test_autotune_keeps_results(gpu, oracle):
             gpu.memcpy_dtoh(out, buf)
             assert np.max(np.abs(out.astype(np.float32) - exp)) < 1e-3
         g.close()
+
+
+def test_fp16_is_exactly_rne_of_the_fp32_output(gpu):
+    """b16 output == RN-even(b32 output), bit for bit (the reference's
+    __floats2half2_rn of the same fp32 value, BeamformerKernels.cu:113,182): the fp16
+    mode adds one correctly rounded conversion and nothing else."""
+    from dc_sand_amd import BeamformerParameters
+
+    for (A, B, C) in ((64, 16, 64), (5, 7, 33), (2, 300, 40)):
+        bp = BeamformerParameters(NR_CHANNELS=C, NR_STATIONS=A, NR_BEAMS=B)
+        table = rand_table(bp.n_pairs, seed=C)
+        f32 = _gen(gpu, bp, table, 9, 3, bitwidth=1)
+        f16 = _gen(gpu, bp, table, 9, 3, bitwidth=0)
+        assert np.array_equal(f16.view(np.uint16), f32.astype(np.float16).view(np.uint16))
