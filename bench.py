@@ -46,6 +46,7 @@ def parse():
     ap.add_argument("--beams-per-gpu", type=int, default=BEAMS_PER_GPU)
     ap.add_argument("--chan", type=int, default=CHAN)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the fp16 / fused-beamformer side measurements (N = 1)")
     ap.add_argument("--no-autotune", action="store_true",
                     help="keep the library's default launch geometry instead of letting dcs_bf_autotune measure it in the "
                          "untimed set-up (its trial launches run under separate kernel symbols, template TAG = 1, so a "
@@ -85,6 +86,45 @@ def cpu_baseline(bp, table, seconds: float) -> dict:
         out["all_cores"] = {"value": nc_mt * n_pairs / s2 / 1e9, "cores": nt_threads,
                             "sample": f"channels [0,{nc_mt}) in {s2:.2f} s"}
     return out
+
+
+def extras(gen, bp, out, out_bytes, sh, device) -> dict:
+    """Side measurements after the timed region (N = 1): the fp16 output mode of the same
+    workload and the fused coefficient-generation + beamforming kernel
+    (f1) on a 64 x 64 x 4096 x 64 problem.  Same HIP-event method, 20 launches each."""
+    from dc_sand_amd import BeamformerParameters
+    from dc_sand_amd.generator import SteeringCoefficientGenerator, simulate_input
+
+    def timed(fn, n=20, warm=5):
+        for _ in range(warm):
+            fn()
+        e0, e1 = device.Event(), device.Event()
+        e0.record(sh)
+        for _ in range(n):
+            fn()
+        e1.record(sh)
+        e1.synchronize()
+        return e1.elapsed_ms_since(e0) / n
+
+    res = {}
+    gen.set_tuning()
+    nb16 = gen.output_bytes(0, 1)
+    ms = timed(lambda: gen.generate(out.data_ptr(), nb16, t0=1, nt=1, bitwidth=0, stream=sh))
+    res["fp16_output"] = {"value": bp.coeffs_per_time_step() / ms / 1e6, "unit": "Gcoeff/s", "ms": ms,
+                          "hbm_GBps": nb16 / ms / 1e6, "bound": "fp32 VALU (4 B written per coefficient)"}
+    A, B, C, nt = 64, 64, 4096, 64
+    fp = BeamformerParameters(NR_CHANNELS=C, NR_STATIONS=A, NR_BEAMS=B, NR_SAMPLES_PER_CHANNEL=nt)
+    g = SteeringCoefficientGenerator(fp)
+    g.upload_delays(simulate_input(fp), stream=sh)
+    ant_bytes, beam_bytes = A * C * nt * 2, B * C * nt * 8
+    d_ant, d_beams = device.mem_alloc(ant_bytes), device.mem_alloc(beam_bytes)
+    device.memset(d_ant, 3, ant_bytes, stream=sh)
+    ms = timed(lambda: g.generate_and_beamform(d_ant, ant_bytes, d_beams, beam_bytes, 0, nt, stream=sh))
+    res["fused_generate_and_beamform"] = {"value": A * B * C * nt / ms / 1e6, "unit": "G coefficient-products/s", "ms": ms,
+                                          "shape": f"{A}ant x {B}beam x {C}chan x {nt}samples", "bound": "fp32 VALU (no coefficient reaches HBM)"}
+    device.stream_synchronize(sh)
+    g.close()
+    return res
 
 
 def pmc_traffic(bytes_algo: int):
@@ -278,6 +318,8 @@ def main():
                 "algorithmic_bytes_per_launch": algo_bytes,
             },
         }
+        if N == 1 and not args.no_extras:
+            result["also_measured"] = extras(gen, bp, out, out_bytes, sh, device)
         if N == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(bp, np.ascontiguousarray(table_host), args.cpu_seconds)
             mx, n_over = spot_check()
