@@ -618,3 +618,47 @@ def test_fp16_is_exactly_rne_of_the_fp32_output(gpu):
         f32 = _gen(gpu, bp, table, 9, 3, bitwidth=1)
         f16 = _gen(gpu, bp, table, 9, 3, bitwidth=0)
         assert np.array_equal(f16.view(np.uint16), f32.astype(np.float16).view(np.uint16))
+
+
+@pytest.mark.parametrize("form", [1, 2])
+def test_many_time_steps_cross_the_internal_chunking(gpu, oracle, form):
+    """nt = 5000 > the 4096 fDeltaTime values staged per launch: the call is split into
+    several launches internally; every time step must still be the oracle's."""
+    from dc_sand_amd import BeamformerParameters
+
+    bp = BeamformerParameters(NR_CHANNELS=5, NR_STATIONS=3, NR_BEAMS=6)
+    table = rand_table(bp.n_pairs, seed=99)
+    op = oracle.params_from(bp)
+    got = _gen(gpu, bp, table, 250, 5000, tuning=dict(form=form))
+    _check(oracle, got, oracle.generate(op, table, 250, 5000))
+
+
+@pytest.mark.parametrize("form", [1, 2])
+@pytest.mark.parametrize("bitwidth", [1, 0])
+def test_output_pointer_not_16_byte_aligned(gpu, oracle, form, bitwidth):
+    """An output tensor that starts 8 (fp32) or 4 (fp16) bytes off a 16-byte boundary
+    takes the per-pair store path; the bytes before and after it stay untouched."""
+    from dc_sand_amd import BeamformerParameters
+    from dc_sand_amd.generator import SteeringCoefficientGenerator
+
+    bp = BeamformerParameters(NR_CHANNELS=19, NR_STATIONS=4, NR_BEAMS=34)
+    table = rand_table(bp.n_pairs, seed=5)
+    g = SteeringCoefficientGenerator(bp)
+    g.set_tuning(form=form)
+    g.upload_delays(table)
+    eb = 8 if bitwidth == 1 else 4
+    nbytes = 2 * bp.NR_CHANNELS * bp.n_pairs * eb
+    buf = gpu.mem_alloc(nbytes + 64)
+    gpu.memset(buf, 0xFF, nbytes + 64)
+    g.generate(int(buf) + eb, nbytes, t0=3, nt=2, bitwidth=bitwidth)
+    host = np.empty(nbytes + 64, dtype=np.uint8)
+    gpu.memcpy_dtoh(host, buf)
+    assert np.all(host[:eb] == 0xFF) and np.all(host[eb + nbytes:] == 0xFF)
+    exp = oracle.generate(oracle.params_from(bp), table, 3, 2)
+    if bitwidth == 1:
+        got = host[eb:eb + nbytes].copy().view(np.float32).reshape(exp.shape)
+        _check(oracle, got, exp)
+    else:
+        got = host[eb:eb + nbytes].copy().view(np.float16).reshape(exp.shape)
+        assert np.max(np.abs(got.astype(np.float32) - exp)) < 1e-3
+    g.close()
