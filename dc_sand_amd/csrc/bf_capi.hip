@@ -615,7 +615,6 @@ int dcs_bf_generate_and_beamform(dcs_bf_context *c, uint64_t t0, uint32_t nt, co
     if ((t0 % 16u) || (nt % 16u)) return DCS_ERR_INVALID_ARGUMENT; // INTERNAL_TIME_SAMPLES, BeamformerParameters.h:51
     if (!c->table_set) return DCS_ERR_NOT_READY;
     const uint32_t A = (uint32_t)c->p.nr_stations, B = (uint32_t)c->p.nr_beams, C = (uint32_t)c->p.nr_channels;
-    if (A > 2048u) return DCS_ERR_UNSUPPORTED; // one [A][16][2] int8 block must fit the LDS staging buffer
     // BeamformerCoefficientTest.cu:25-26 (sizes of the antenna and beam tensors)
     if (antenna_bytes < (size_t)A * C * nt * 2u) return DCS_ERR_INVALID_ARGUMENT;
     if (beams_bytes < (size_t)B * C * nt * 2u * sizeof(float)) return DCS_ERR_INVALID_ARGUMENT;

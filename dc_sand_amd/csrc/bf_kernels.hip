@@ -441,10 +441,11 @@ __global__ void __launch_bounds__(kBlock) bf_bform_terms_kernel(const bf_bform_t
 
 // CH channels per pass: a lane's terms load and the LDS sample reads are shared by CH
 // independent coefficient chains (more ILP, fewer loads per product).
+constexpr uint32_t kAntChunk = 128; // antennas staged in LDS at a time (as fp32: 16 KiB per channel)
 template <int CH>
 __global__ void __launch_bounds__(kBlock) bf_beamform_kernel(const bf_beamform_args a)
 {
-    extern __shared__ __attribute__((aligned(16))) int8_t s_ant[]; // [CH][A][16][2]
+    extern __shared__ __attribute__((aligned(16))) float s_ant[]; // [CH][A][16][2], int8 samples converted once
 
     const uint32_t bid = blockIdx.x;
     const uint32_t bg = bid % a.n_bgroups;
@@ -468,18 +469,9 @@ __global__ void __launch_bounds__(kBlock) bf_beamform_kernel(const bf_beamform_a
     const uint32_t cend = min(cbeg + a.chan_per_block, a.C);
     const uint32_t tex_g = a.tex0 + tex; // 16-sample block within the whole tensor
     const uint32_t words = a.A * 8u;     // dwords of one [A][16][2] int8 block
+    const uint32_t sa = min(kAntChunk, a.A); // antennas per staged chunk = stride of a channel's LDS region
 
     for (uint32_t c = cbeg; c < cend; c += CH) {
-        __syncthreads(); // previous pass's readers are done
-#pragma unroll
-        for (int h = 0; h < CH; h++) {
-            if (c + h < cend) {
-                const uint32_t *src = reinterpret_cast<const uint32_t *>(a.ant) + ((uint64_t)(c + h) * a.nt16_total + tex_g) * words;
-                for (uint32_t i = threadIdx.x; i < words; i += kBlock) reinterpret_cast<uint32_t *>(s_ant)[h * words + i] = src[i];
-            }
-        }
-        __syncthreads();
-
         float fChan[CH], acc_re[CH], acc_im[CH];
 #pragma unroll
         for (int h = 0; h < CH; h++) {
@@ -487,38 +479,60 @@ __global__ void __launch_bounds__(kBlock) bf_beamform_kernel(const bf_beamform_a
             acc_re[h] = 0.0f;
             acc_im[h] = 0.0f;
         }
-        auto sample = [&](int h, uint32_t ant, float &sre, float &sim) {
-            const int8_t *sp = s_ant + ((size_t)h * a.A + ant) * 32u + t_in * 2u;
-            sre = (float)sp[0];
-            sim = (float)sp[1];
-        };
-        if (!slow) {
-            dispatch_fast(a.k.uDiv3Exact != 0u, !high, [&](auto div3, auto lowdeg) {
-#pragma unroll 2
-                for (uint32_t ant = 0; ant < a.A; ant++) {
-                    const floatx2 kp = *reinterpret_cast<const floatx2 *>(tp + 2u * (uint64_t)ant * a.B);
+        // antennas in chunks of kAntChunk (the LDS staging buffer); the running sums carry
+        // across chunks, so the summation order stays the verifier's (a = 0, 1, 2, ...)
+        for (uint32_t a0 = 0; a0 < a.A; a0 += kAntChunk) {
+            const uint32_t na = min(kAntChunk, a.A - a0);
+            const uint32_t cw = na * 8u; // dwords of this chunk's [na][16][2] int8 block
+            __syncthreads();             // previous chunk's readers are done
 #pragma unroll
+            for (int h = 0; h < CH; h++) {
+                if (c + h < cend) {
+                    const uint32_t *src = reinterpret_cast<const uint32_t *>(a.ant) +
+                                          ((uint64_t)(c + h) * a.nt16_total + tex_g) * words + (uint64_t)a0 * 8u;
+                    for (uint32_t i = threadIdx.x; i < cw; i += kBlock) {
+                        const uint32_t w = src[i]; // {re, im, re, im} of two consecutive (antenna, time) samples
+                        const floatx4 f = {(float)(int8_t)(w & 0xffu), (float)(int8_t)((w >> 8) & 0xffu),
+                                           (float)(int8_t)((w >> 16) & 0xffu), (float)(int8_t)(w >> 24)};
+                        *reinterpret_cast<floatx4 *>(&s_ant[((size_t)h * sa * 8u + i) * 4u]) = f;
+                    }
+                }
+            }
+            __syncthreads();
+
+            auto sample = [&](int h, uint32_t al, float &sre, float &sim) {
+                const floatx2 v = *reinterpret_cast<const floatx2 *>(&s_ant[(((size_t)h * sa + al) * 16u + t_in) * 2u]);
+                sre = v.x;
+                sim = v.y;
+            };
+            if (!slow) {
+                dispatch_fast(a.k.uDiv3Exact != 0u, !high, [&](auto div3, auto lowdeg) {
+#pragma unroll 2
+                    for (uint32_t al = 0; al < na; al++) {
+                        const floatx2 kp = *reinterpret_cast<const floatx2 *>(tp + 2u * (uint64_t)(a0 + al) * a.B);
+#pragma unroll
+                        for (int h = 0; h < CH; h++) {
+                            float re, im, sre, sim;
+                            coeff_fast<decltype(div3)::value, decltype(lowdeg)::value>(kp.x, kp.y, fChan[h], D, y, re, im);
+                            sample(h, al, sre, sim);
+                            const float pr = re * sre, pi = im * sim; // product, then sum: two roundings each
+                            acc_re[h] = acc_re[h] + pr;
+                            acc_im[h] = acc_im[h] + pi;
+                        }
+                    }
+                });
+            } else {
+                for (uint32_t al = 0; al < na; al++) {
+                    const floatx2 kp = *reinterpret_cast<const floatx2 *>(tp + 2u * (uint64_t)(a0 + al) * a.B);
+#pragma unroll 1
                     for (int h = 0; h < CH; h++) {
                         float re, im, sre, sim;
-                        coeff_fast<decltype(div3)::value, decltype(lowdeg)::value>(kp.x, kp.y, fChan[h], D, y, re, im);
-                        sample(h, ant, sre, sim);
-                        const float pr = re * sre, pi = im * sim; // product, then sum: two roundings each
+                        coeff_slow(kp.x, kp.y, fChan[h], D, re, im);
+                        sample(h, al, sre, sim);
+                        const float pr = re * sre, pi = im * sim;
                         acc_re[h] = acc_re[h] + pr;
                         acc_im[h] = acc_im[h] + pi;
                     }
-                }
-            });
-        } else {
-            for (uint32_t ant = 0; ant < a.A; ant++) {
-                const floatx2 kp = *reinterpret_cast<const floatx2 *>(tp + 2u * (uint64_t)ant * a.B);
-#pragma unroll 1
-                for (int h = 0; h < CH; h++) {
-                    float re, im, sre, sim;
-                    coeff_slow(kp.x, kp.y, fChan[h], D, re, im);
-                    sample(h, ant, sre, sim);
-                    const float pr = re * sre, pi = im * sim;
-                    acc_re[h] = acc_re[h] + pr;
-                    acc_im[h] = acc_im[h] + pi;
                 }
             }
         }
@@ -931,9 +945,10 @@ hipError_t bf_launch_beamform(const bf_beamform_args &a_in, hipStream_t stream)
     a.n_cblocks = (a.C + a.chan_per_block - 1) / a.chan_per_block;
     const uint64_t blocks = (uint64_t)a.n_bgroups * a.n_cblocks * a.nt16;
     // two channels per pass (CH = 4 measured no better: profiles/r01_fused.md)
-    const int ch = (a.chan_per_block >= 2 && a.A <= 1024u) ? 2 : 1;
-    const size_t lds = (size_t)a.A * 32u * (size_t)ch;
-    if (blocks > 0x7fffffffull || lds > 64u * 1024u) return hipErrorInvalidValue;
+    const int ch = a.chan_per_block >= 2 ? 2 : 1;
+    const uint32_t na = a.A < kAntChunk ? a.A : kAntChunk;
+    const size_t lds = (size_t)na * 32u * sizeof(float) * (size_t)ch;
+    if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
     if (ch == 2)
         hipLaunchKernelGGL(bf_beamform_kernel<2>, dim3((uint32_t)blocks), dim3(kBlock), lds, stream, a);
     else
