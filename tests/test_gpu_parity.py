@@ -662,3 +662,28 @@ def test_output_pointer_not_16_byte_aligned(gpu, oracle, form, bitwidth):
         got = host[eb:eb + nbytes].copy().view(np.float16).reshape(exp.shape)
         assert np.max(np.abs(got.astype(np.float32) - exp)) < 1e-3
     g.close()
+
+
+def test_fused_with_time_offset(gpu, oracle):
+    """generate_and_beamform(t0 = 32, nt = 32) equals the last two 16-sample blocks of the
+    verifier's 64-sample tensor (the time index is absolute)."""
+    from dc_sand_amd import BeamformerParameters
+    from dc_sand_amd.generator import SteeringCoefficientGenerator
+
+    A, B, C = 12, 20, 6
+    bp = BeamformerParameters(NR_CHANNELS=C, NR_STATIONS=A, NR_BEAMS=B, NR_SAMPLES_PER_CHANNEL=64)
+    op = oracle.params_from(bp)
+    table = rand_table(bp.n_pairs, seed=17)
+    ant_full = np.random.default_rng(9).integers(-128, 128, size=(C, 4, A, 16, 2), dtype=np.int8)
+    exp = oracle.beamform(op, table, 64, ant_full)[:, 2:4]
+    ant = np.ascontiguousarray(ant_full[:, 2:4])
+    g = SteeringCoefficientGenerator(bp)
+    g.upload_delays(table)
+    d_ant = gpu.mem_alloc(ant.nbytes)
+    gpu.memcpy_htod(d_ant, ant)
+    got = np.empty((C, 2, B, 16, 2), dtype=np.float32)
+    d_beams = gpu.mem_alloc(got.nbytes)
+    g.generate_and_beamform(d_ant, ant.nbytes, d_beams, got.nbytes, t0=32, nt=32)
+    gpu.memcpy_dtoh(got, d_beams)
+    assert np.abs(got - np.ascontiguousarray(exp)).max() <= 2e-5 * A + 1e-6
+    g.close()
