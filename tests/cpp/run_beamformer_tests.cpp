@@ -107,6 +107,63 @@ struct CoeffTest { // BeamformerCoeffTest for the three coefficient kernels, fp3
     }
 };
 
+// BeamformerCoeffTest, COMBINED_COEFF_GEN_AND_BEAMFORMER_SINGLE_CHANNEL branch
+// (BeamformerCoefficientTest.cu:46-50,82-87,198-204,259-262,272-275,363-414).
+static int run_combined(float tol, float *kernel_ms_out, float *max_diff_out)
+{
+    dcs_bf_params p;
+    DCS_ERRCHK(dcs_bf_default_params(&p));
+    const size_t nt = (size_t)p.nr_samples_per_channel;
+    const size_t antBytes = (size_t)p.nr_stations * p.nr_channels * nt * 2;                  // :25
+    const size_t beamBytes = (size_t)p.nr_beams * p.nr_channels * nt * 2 * sizeof(float);    // :26
+    const size_t n = (size_t)p.nr_stations * p.nr_beams;
+    dcs_delay_vals *hDelays = nullptr;
+    int8_t *hAnt = nullptr;
+    float *hBeams = nullptr;
+    void *dAnt = nullptr, *dBeams = nullptr;
+    dcs_bf_context *ctx = nullptr;
+    DCS_ERRCHK(dcs_host_alloc((void **)&hDelays, n * sizeof(dcs_delay_vals)));
+    DCS_ERRCHK(dcs_host_alloc((void **)&hAnt, antBytes));
+    DCS_ERRCHK(dcs_host_alloc((void **)&hBeams, beamBytes));
+    DCS_ERRCHK(dcs_malloc(&dAnt, antBytes));
+    DCS_ERRCHK(dcs_malloc(&dBeams, beamBytes));
+    DCS_ERRCHK(dcs_bf_create(&p, &ctx));
+    DCS_ERRCHK(dcs_bf_simulate_input(&p, hDelays));                              // simulate_input :185-196
+    for (size_t i = 0; i < antBytes; i++) hAnt[i] = static_cast<int8_t>(i);      // :198-204
+    DCS_ERRCHK(dcs_bf_upload_delays(ctx, hDelays, nullptr));                     // transfer_HtoD
+    DCS_ERRCHK(dcs_memcpy_htod(dAnt, hAnt, antBytes, nullptr));
+    void *e0, *e1;
+    DCS_ERRCHK(dcs_event_create(&e0));
+    DCS_ERRCHK(dcs_event_create(&e1));
+    DCS_ERRCHK(dcs_event_record(e0, nullptr));
+    DCS_ERRCHK(dcs_bf_generate_and_beamform(ctx, 0, (uint32_t)nt, (const int8_t *)dAnt, antBytes, (float *)dBeams, beamBytes, nullptr));
+    DCS_ERRCHK(dcs_event_record(e1, nullptr));
+    DCS_ERRCHK(dcs_event_synchronize(e1));
+    DCS_ERRCHK(dcs_event_elapsed_ms(e0, e1, kernel_ms_out));
+    DCS_ERRCHK(dcs_memcpy_dtoh(hBeams, dBeams, beamBytes, nullptr));             // transfer_DtoH
+    DCS_ERRCHK(dcs_stream_synchronize(nullptr));
+    dcs_oracle_params op = {p.nr_channels, p.nr_stations, p.nr_beams, p.sampling_period, p.fft_size};
+    std::vector<float> expect(beamBytes / sizeof(float));
+    dcs_oracle_beamform(&op, (const dcs_oracle_delay_vals *)hDelays, nt, hAnt, expect.data());   // verify_output :363-414
+    float mx = 0;
+    int result = 1;
+    for (size_t i = 0; i < expect.size(); i++) {
+        const float d = std::fabs(hBeams[i] - expect[i]);
+        if (d > mx) mx = d;
+        if (!(d <= tol)) result = -1;
+    }
+    *max_diff_out = mx;
+    dcs_event_destroy(e0);
+    dcs_event_destroy(e1);
+    dcs_bf_destroy(ctx);
+    dcs_free(dAnt);
+    dcs_free(dBeams);
+    dcs_host_free(hAnt);
+    dcs_host_free(hBeams);
+    dcs_host_free(hDelays);
+    return result;
+}
+
 int main()
 {
     int ndev = 0;
@@ -124,6 +181,14 @@ int main()
         {"Multiple Channels", DCS_BF_MULTIPLE_CHANNELS, 1e-4f},
         {"Naive Implementation", DCS_BF_NAIVE, 1e-4f}, // :61
     };
+    {
+        float ms = 0, mx = 0;
+        if (run_combined(1e-1f, &ms, &mx) != 1) { // runBeamformerTests.cpp:15
+            std::printf("Test failed, output data not generated correctly\n");
+            return 1;
+        }
+        std::printf("%-50s kernel %.3f ms, max |beam - CPU verifier| %g (tolerance 0.1)\n", "Combined Steering Coeffs+Beamforming", ms, mx);
+    }
     std::printf("%-50s%-20s%-20s%-10s\n", "Kernel Name", "GPU Utilisation", "GPU Utilisation", "max ULP");
     for (const Case &c : cases) {
         CoeffTest t(c.tol, c.kernel);

@@ -542,7 +542,7 @@ def test_cpp_host_against_c_abi(gpu):
     run = subprocess.run([str(d / "run_beamformer_tests")], capture_output=True, text=True, timeout=600)
     assert run.returncode == 0, run.stdout + run.stderr
     assert run.stdout.count("CPU took") == 3
-    for name in ("Multiple Chans+Timestamps", "Multiple Channels", "Naive Implementation"):
+    for name in ("Combined Steering Coeffs+Beamforming", "Multiple Chans+Timestamps", "Multiple Channels", "Naive Implementation"):
         assert name in run.stdout
 
 
