@@ -10,7 +10,7 @@ R = "/root/repo/"
 tag, bench_json, rnd = sys.argv[1], sys.argv[2], sys.argv[3]  # e.g. prof5 bench5.json r01
 f = glob.glob(R + f"gpurun_out/{tag}_kt/runc/*_kernel_trace.csv")[0]
 PROD = "false, 0>(bf_tiled_args)"  # production symbol; dcs_bf_autotune's trial launches run as <..., 1>
-rows = [r for r in csv.DictReader(open(f)) if "bf_tiled_kernel" in r["Kernel_Name"] and PROD in r["Kernel_Name"]]
+rows = [r for r in csv.DictReader(open(f)) if "bf_tiled_kernel<false," in r["Kernel_Name"] and PROD in r["Kernel_Name"]]
 bench_rows = rows[-60:]  # 10 warm-up + 50 timed
 d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in bench_rows]
 timed = d[10:]
@@ -26,7 +26,7 @@ b = json.loads(open(R + "gpurun_out/" + bench_json).read())
 res = {}
 for d_, name in ((f"{tag}_pmc_w", "WRITE_SIZE"), (f"{tag}_pmc_f", "FETCH_SIZE")):
     ff = glob.glob(R + f"gpurun_out/{d_}/runc/*_counter_collection.csv")[0]
-    v = [float(r["Counter_Value"]) for r in csv.DictReader(open(ff)) if "bf_tiled_kernel" in r["Kernel_Name"] and PROD in r["Kernel_Name"] and r["Counter_Name"] == name]
+    v = [float(r["Counter_Value"]) for r in csv.DictReader(open(ff)) if "bf_tiled_kernel<false," in r["Kernel_Name"] and PROD in r["Kernel_Name"] and r["Counter_Name"] == name]
     res[name] = (len(v), st.mean(v))
     shutil.copy(ff, R + f"profiles/{rnd}_pmc_{name.lower()}_counter_collection.csv")
 algo = 17179869184
