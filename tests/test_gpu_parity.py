@@ -687,3 +687,37 @@ def test_fused_with_time_offset(gpu, oracle):
     gpu.memcpy_dtoh(got, d_beams)
     assert np.abs(got - np.ascontiguousarray(exp)).max() <= 2e-5 * A + 1e-6
     g.close()
+
+
+def test_config5_streaming_at_the_200us_slab(gpu, oracle):
+    """BASELINE configs[4] at size: 64 x 1024 pairs x the 2560-channel slab that sustains the
+    200 us cadence (1.34 GB per tick), hipGraph replay, a new delay table landing between
+    ticks; sampled rows of every tick against the oracle."""
+    from dc_sand_amd import BeamformerParameters
+    from dc_sand_amd.generator import SteeringCoefficientGenerator
+
+    bp = BeamformerParameters(NR_CHANNELS=32768, NR_STATIONS=64, NR_BEAMS=1024)
+    op = oracle.params_from(bp)
+    c0, nc = 4096, 2560
+    tables = [rand_table(bp.n_pairs, seed=s) for s in (61, 62)]
+    g = SteeringCoefficientGenerator(bp)
+    g.upload_delays(tables[0])
+    nbytes = nc * bp.n_pairs * 8
+    buf = gpu.mem_alloc(nbytes)
+    stream = gpu.Stream()
+    st = g.stream_begin(buf, nbytes, c0, nc, stream)
+    row = bp.n_pairs * 8
+    host = np.empty((bp.NR_STATIONS, bp.NR_BEAMS, 2), dtype=np.float32)
+    cur = 0
+    for tick, t in enumerate([7, 8, 9, 300]):
+        new = None
+        if tick == 2:
+            cur, new = 1, tables[1]
+        st.tick(t, new)
+        stream.synchronize()
+        for cl in (0, 1279, nc - 1):
+            gpu.memcpy_dtoh(host, int(buf) + cl * row)
+            exp = oracle.generate(op, tables[cur], t, 1, c0 + cl, 1)
+            assert oracle.max_ulp(host, exp, 1)[1] == 0, (tick, t, cl)
+    st.end()
+    g.close()
