@@ -638,7 +638,8 @@ __global__ void __launch_bounds__(1024) bf_probe_pattern_kernel(uintx4 *out, uin
     const uint32_t nq = (cols + QB - 1) / QB, nr = (rows + RB - 1) / RB;
     uint32_t b = blockIdx.x;
     const uint32_t G = gridDim.x;
-    if (xcd && (G % 8u) == 0u) b = (b % 8u) * (G / 8u) + b / 8u;
+    const uint32_t rot = xcd >> 4; // probe: rotate the rectangle column within groups of 8 (XCD <-> address affinity)
+    if ((xcd & 1u) && (G % 8u) == 0u) b = (b % 8u) * (G / 8u) + b / 8u;
     uint32_t rq, rr;
     if (order == 0) {
         rq = b % nq;
@@ -647,6 +648,7 @@ __global__ void __launch_bounds__(1024) bf_probe_pattern_kernel(uintx4 *out, uin
         rr = b % nr;
         rq = b / nr;
     }
+    if (rot && (nq % 8u) == 0u) rq = (rq & ~7u) | ((rq + rot) & 7u);
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const uintx4 v = {0x3f800000u, b, 0x3f800000u, lane};
     const uint32_t nk = QB * RB;
