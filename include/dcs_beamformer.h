@@ -207,7 +207,9 @@ int dcs_bf_set_tuning(dcs_bf_context *ctx, const struct dcs_bf_tuning *t);
  * delay table currently set) and keep the fastest: the optimum is sharp and moves with
  * shape and arithmetic form (profiles/r01_geometry_sweep.md).  Generates channels
  * [0, min(nr_channels, out_bytes / row)) of time index 1 into d_out repeatedly
- * (~60 launches); blocks on events, so it cannot be captured in a graph.  The chosen
+ * (14 trial geometries x 2 rounds; each trial first settles ~20 ms on its own geometry, because the
+ * first launches after a change of access pattern run slower, then times ~3 ms: < 1 s in all);
+ * blocks on events, so it cannot be captured in a graph.  The chosen
  * knobs are written to *chosen (may be NULL) and stay in effect for this context.
  * Results do not depend on the geometry (every one gives the same bits). */
 int dcs_bf_autotune(dcs_bf_context *ctx, int bitwidth, void *d_out, size_t out_bytes, void *stream,
