@@ -507,9 +507,18 @@ __global__ void __launch_bounds__(kBlock) bf_beamform_kernel(const bf_beamform_a
             };
             if (!slow) {
                 dispatch_fast(a.k.uDiv3Exact != 0u, !high, [&](auto div3, auto lowdeg) {
+                    // terms of antenna al+2 are requested while al is computed (L2 latency >> one step)
+                    constexpr uint32_t kAhead = 2;
+                    floatx2 q[kAhead];
+#pragma unroll
+                    for (uint32_t i = 0; i < kAhead; i++)
+                        q[i] = *reinterpret_cast<const floatx2 *>(tp + 2u * (uint64_t)(a0 + min(i, na - 1u)) * a.B);
 #pragma unroll 2
                     for (uint32_t al = 0; al < na; al++) {
-                        const floatx2 kp = *reinterpret_cast<const floatx2 *>(tp + 2u * (uint64_t)(a0 + al) * a.B);
+                        const floatx2 kp = q[0];
+#pragma unroll
+                        for (uint32_t i = 0; i + 1 < kAhead; i++) q[i] = q[i + 1];
+                        q[kAhead - 1] = *reinterpret_cast<const floatx2 *>(tp + 2u * (uint64_t)(a0 + min(al + kAhead, na - 1u)) * a.B);
 #pragma unroll
                         for (int h = 0; h < CH; h++) {
                             float re, im, sre, sim;
