@@ -727,8 +727,10 @@ int dcs_bf_autotune(dcs_bf_context *c, int bitwidth, void *d_out, size_t out_byt
     if (e0) (void)hipEventDestroy(e0);
     if (e1) (void)hipEventDestroy(e1);
     c->tune = saved;
-    c->tuning_now = false;
-    if (st != 0) return st;
+    if (st != 0) {
+        c->tuning_now = false;
+        return st;
+    }
     int best = 0;
     for (int i = 1; i < ncand; i++)
         if (cands[i].best_ms < cands[best].best_ms) best = i;
@@ -736,6 +738,10 @@ int dcs_bf_autotune(dcs_bf_context *c, int bitwidth, void *d_out, size_t out_byt
     c->tune.tiles_per_block = cands[best].tpb;
     c->tune.chan_per_block = cands[best].cpb;
     c->tune.nontemporal = 1;
+    // leave the device settled on the chosen geometry (still under the tuner's kernel symbols)
+    for (int k = 0; k < n_settle && st == 0; k++) st = dcs_bf_generate_slab(c, bitwidth, 1, 1, 0, nc, d_out, out_bytes, stream);
+    c->tuning_now = false;
+    if (st != 0) return st;
     if (chosen) *chosen = c->tune;
     return DCS_OK;
 }
