@@ -955,12 +955,15 @@ hipError_t bf_launch_beamform(const bf_beamform_args &a_in, hipStream_t stream)
     a.n_bgroups = (a.B + 15u) / 16u;
     a.n_cblocks = (a.C + a.chan_per_block - 1) / a.chan_per_block;
     const uint64_t blocks = (uint64_t)a.n_bgroups * a.n_cblocks * a.nt16;
-    // two channels per pass (CH = 4 measured no better: profiles/r01_fused.md)
-    const int ch = a.chan_per_block >= 2 ? 2 : 1;
+    // channels per pass: 4 while the staged samples stay within 32 KiB of LDS per workgroup
+    // (<= 64 antennas), else 2 (profiles/r01_fused.md)
     const uint32_t na = a.A < kAntChunk ? a.A : kAntChunk;
+    const int ch = (a.chan_per_block >= 4 && na <= 64u) ? 4 : (a.chan_per_block >= 2 ? 2 : 1);
     const size_t lds = (size_t)na * 32u * sizeof(float) * (size_t)ch;
     if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
-    if (ch == 2)
+    if (ch == 4)
+        hipLaunchKernelGGL(bf_beamform_kernel<4>, dim3((uint32_t)blocks), dim3(kBlock), lds, stream, a);
+    else if (ch == 2)
         hipLaunchKernelGGL(bf_beamform_kernel<2>, dim3((uint32_t)blocks), dim3(kBlock), lds, stream, a);
     else
         hipLaunchKernelGGL(bf_beamform_kernel<1>, dim3((uint32_t)blocks), dim3(kBlock), lds, stream, a);
