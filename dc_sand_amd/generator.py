@@ -13,7 +13,7 @@ from ctypes import byref, c_float, c_size_t, c_void_p
 import numpy as np
 
 from . import _lib
-from ._lib import B16, B32, MULTIPLE_CHANNELS_AND_TIMESTAMPS, check
+from ._lib import B32, MULTIPLE_CHANNELS_AND_TIMESTAMPS, check
 from .device import _s
 from .parameters import BeamformerParameters, delay_vals_dtype
 
