@@ -662,7 +662,11 @@ __global__ void __launch_bounds__(1024) bf_probe_pattern_kernel(uintx4 *out, uin
     const uintx4 v = {0x3f800000u, b, 0x3f800000u, lane};
     const uint32_t nk = QB * RB;
     const uint32_t nwaves = blockDim.x >> 6;
-    for (uint32_t k = wave; k < nk; k += nwaves) {
+    const bool contiguous = (xcd & 2u) != 0u; // a wave takes consecutive chunks instead of every nwaves-th
+    const uint32_t per = (nk + nwaves - 1) / nwaves;
+    for (uint32_t j = 0; j < per; j++) {
+        const uint32_t k = contiguous ? wave * per + j : wave + j * nwaves;
+        if (k >= nk) break;
         const uint32_t r = rr * RB + k / QB, q = rq * QB + k % QB;
         if (r < rows && q < cols) store_global<NT>(out + ((uint64_t)r * cols + q) * 64u + lane, v);
     }

@@ -242,8 +242,11 @@ int dcs_probe_sincos(int which, const float *d_x, size_t n, float *d_sin, float 
  * measured HBM-write ceiling the roofline fraction is read against. */
 int dcs_probe_fill(void *d_out, size_t bytes, int nontemporal, void *stream);
 /* Store-only kernel over a `rows` x `cols_kib` KiB matrix: each workgroup owns a
- * rectangle of rb rows x qb KiB (tools/explore.py maps out which write patterns
- * the HBM system sustains; see DESIGN.md "write patterns"). */
+ * rectangle of rb rows x qb KiB (tools/explore_patterns.py maps out which write
+ * patterns the HBM system sustains; profiles/r01_store_patterns.md).  xcd_remap is a
+ * bit set: 1 = workgroups sharing blockIdx % 8 take consecutive rectangles, 2 = a wave
+ * takes consecutive 1-KiB chunks instead of every n-th, bits 4-6 = rotate the rectangle
+ * column within groups of 8 (XCD <-> address affinity probe). */
 int dcs_probe_store_pattern(void *d_out, uint32_t rows, uint32_t cols_kib, uint32_t qb, uint32_t rb, int order,
                             int xcd_remap, int nontemporal, uint32_t block_threads, void *stream);
 
