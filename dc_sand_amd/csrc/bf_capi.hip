@@ -98,7 +98,7 @@ struct dcs_bf_context {
     // row-streaming form: per-(time step, pair) terms table + slow-path flags
     uint32_t pairs_pad;     // n_pairs rounded up to 256
     uint32_t terms_steps;   // time steps the table holds
-    float *d_terms;         // [terms_steps][pairs_pad][2]
+    float *d_terms;         // [terms_steps][pairs_pad][2]; allocated on first use (ensure_terms)
     uint32_t *d_flags;      // [terms_steps][pairs_pad/64]
     dcs_bf_tuning tune;
 };
@@ -320,8 +320,6 @@ int dcs_bf_create(const dcs_bf_params *p, dcs_bf_context **out)
         const size_t db = (size_t)kDtSlots * kDtSlotFloats * sizeof(float);
         if ((st = (int)hipMalloc((void **)&c->d_dt, db)) != 0) break;
         if ((st = (int)hipHostMalloc((void **)&c->h_dt, db, hipHostMallocDefault)) != 0) break;
-        if ((st = (int)hipMalloc((void **)&c->d_terms, (size_t)c->terms_steps * c->pairs_pad * 8u)) != 0) break;
-        if ((st = (int)hipMalloc((void **)&c->d_flags, (size_t)c->terms_steps * (c->pairs_pad / 64u) * 4u)) != 0) break;
         for (int i = 0; i < kDtSlots && st == 0; i++) st = (int)hipEventCreateWithFlags(&c->dt_ev[i], hipEventDisableTiming);
         if (st != 0) break;
         // first use of the pinned->device copy path costs ~0.25 ms once: pay it here,
@@ -461,11 +459,23 @@ int launch_tiled(dcs_bf_context *c, bool out16, const float *dt_dev, float dt0, 
     return (int)hipLaunchKernel(l.func, l.grid, l.block, params, 0, stream);
 }
 
+// The terms table (up to 64 MiB) is only needed by the rows form and the fused kernel:
+// allocate it when one of them is first used.  Not capturable (hipMalloc), like those paths.
+int ensure_terms(dcs_bf_context *c)
+{
+    if (c->d_terms && c->d_flags) return DCS_OK;
+    if (!c->d_terms) DCS_TRY(hipMalloc((void **)&c->d_terms, (size_t)c->terms_steps * c->pairs_pad * 8u));
+    if (!c->d_flags) DCS_TRY(hipMalloc((void **)&c->d_flags, (size_t)c->terms_steps * (c->pairs_pad / 64u) * 4u));
+    return DCS_OK;
+}
+
 // Row-streaming form: terms pre-pass, then short waves in address order.
 int launch_rows(dcs_bf_context *c, bool out16, const float *dt_dev, float dt0, uint32_t nt, uint32_t c0,
                 uint32_t nc, void *d_out, hipStream_t stream)
 {
     if (nt > c->terms_steps) return DCS_ERR_INVALID_ARGUMENT;
+    int st_alloc = ensure_terms(c);
+    if (st_alloc != DCS_OK) return st_alloc;
     bf_terms_args ta;
     std::memset(&ta, 0, sizeof(ta));
     ta.delays = c->d_table[c->cur];
@@ -621,6 +631,10 @@ int dcs_bf_generate_and_beamform(dcs_bf_context *c, uint64_t t0, uint32_t nt, co
     if ((reinterpret_cast<uintptr_t>(d_antenna) & 3u) || (reinterpret_cast<uintptr_t>(d_beams) & 7u))
         return DCS_ERR_INVALID_ARGUMENT;
     hipStream_t s = as_stream(stream);
+    {
+        int st_alloc = ensure_terms(c);
+        if (st_alloc != DCS_OK) return st_alloc;
+    }
     uint32_t chunk = c->terms_steps & ~15u; // time steps per launch: what the terms table holds
     if (chunk > kDtSlotFloats) chunk = kDtSlotFloats;
     if (chunk == 0) return DCS_ERR_UNSUPPORTED;
