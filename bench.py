@@ -235,10 +235,12 @@ def main():
     torch.cuda.synchronize()
 
     e0, e1 = device.Event(), device.Event()
+    marks = [device.Event() for _ in range(args.steps)]  # one per step: the distribution, not only the mean
     t_start = time.perf_counter()
     e0.record(sh)
-    for k in range(args.warmup, args.warmup + args.steps):
+    for i, k in enumerate(range(args.warmup, args.warmup + args.steps)):
         step(k)
+        marks[i].record(sh)
     e1.record(sh)
     torch.cuda.synchronize()
     if N > 1:
@@ -282,6 +284,7 @@ def main():
         # its own stream over the timed region / launches (one launch per step; the
         # 16-KiB-per-row slice gather is the only other kernel there)
         kern_ms = ev_ms / args.steps
+        per_step = np.diff([0.0] + [m.elapsed_ms_since(e0) for m in marks])
         algo_bytes = 8 * coeffs_per_gpu_step
         achieved = algo_bytes / (kern_ms * 1e-3) / 1e9
         result = {
@@ -315,6 +318,9 @@ def main():
                 "frac": achieved / HBM_PEAK_GBPS,
                 "traffic": pmc_traffic(algo_bytes),
                 "kernel_ms": kern_ms,
+                "kernel_ms_median": float(np.median(per_step)),
+                "kernel_ms_min": float(np.min(per_step)),
+                "kernel_ms_max": float(np.max(per_step)),
                 "algorithmic_bytes_per_launch": algo_bytes,
             },
         }
