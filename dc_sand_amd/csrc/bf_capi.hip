@@ -401,6 +401,7 @@ int dcs_bf_set_tuning(dcs_bf_context *c, const dcs_bf_tuning *t)
     if (t->rows_same_tile < -1 || t->rows_same_tile > 1) return DCS_ERR_INVALID_ARGUMENT;
     if (t->xcd_remap < -1 || t->xcd_remap > 1) return DCS_ERR_INVALID_ARGUMENT;
     if (t->math_mode < 0 || t->math_mode > 3) return DCS_ERR_INVALID_ARGUMENT;
+    if (t->pace < 0 || t->pace > 4096) return DCS_ERR_INVALID_ARGUMENT;
     c->tune = *t;
     // math_mode bit 0: keep the 5-op divide; bit 1: keep the full polynomials
     c->k.uDiv3Exact = (t->math_mode & 1) ? 0u : c->div3_verified;
@@ -446,6 +447,7 @@ int prepare_tiled(dcs_bf_context *c, bool out16, const float *dt_dev, float dt0,
     pick_geometry(c, out16, nc, nt, &tpb, &cpb, &ntstore);
     a.chan_per_block = cpb;
     a.xcd_remap = c->tune.xcd_remap > 0 ? 1u : 0u;
+    a.pace = (uint32_t)c->tune.pace;
     return (int)bf_prepare_tiled(a, out16, tpb | (c->tune.nomath ? 0x100 : 0) | (c->tuning_now ? 0x200 : 0), ntstore, l);
 }
 
@@ -886,7 +888,15 @@ int dcs_probe_store_pattern(void *d_out, uint32_t rows, uint32_t cols_kib, uint3
 {
     if (!d_out) return DCS_ERR_INVALID_ARGUMENT;
     return (int)bf_launch_probe_pattern(d_out, rows, cols_kib, qb, rb, (uint32_t)order, (uint32_t)xcd_remap,
-                                        nontemporal != 0, block_threads, as_stream(stream));
+                                        nontemporal, block_threads, as_stream(stream));
+}
+
+int dcs_probe_one_store(void *d_out, size_t bytes, int store_mode, int stores_per_thread, uint32_t row_bytes, void *stream)
+{
+    if (!d_out || (bytes % 4096u) || stores_per_thread < 1 || stores_per_thread > 64) return DCS_ERR_INVALID_ARGUMENT;
+    if (stores_per_thread > 1 && (row_bytes == 0 || (row_bytes % 1024u) || bytes % ((size_t)row_bytes * 4u * (size_t)stores_per_thread)))
+        return DCS_ERR_INVALID_ARGUMENT;
+    return (int)bf_launch_probe_one_store(d_out, bytes, store_mode, stores_per_thread, row_bytes, as_stream(stream));
 }
 
 int dcs_probe_reduce(const void *d_in, size_t bytes, uint64_t *checksum, float *max_modulus_dev, void *stream)

@@ -22,6 +22,7 @@ struct bf_tiled_args {
     uint32_t n_tile_groups;       // ceil(n_pairs / pairs per workgroup)
     uint32_t n_cblocks;           // ceil(nc / chan_per_block)
     uint32_t xcd_remap;           // workgroups sharing blockIdx % 8 (one XCD) take consecutive (tile, channel block)s
+    uint32_t pace;                // 64-cycle sleeps before each store of the fast loop (tuning knob)
     dcs_bf_consts k;
 };
 
@@ -113,10 +114,12 @@ hipError_t bf_launch_probe_sincos(int which, const float *x, size_t n, float *s,
                                   hipStream_t stream);
 hipError_t bf_launch_probe_fill(void *out, size_t bytes, bool nontemporal, hipStream_t stream);
 hipError_t bf_launch_probe_pattern(void *out, uint32_t rows, uint32_t cols, uint32_t QB, uint32_t RB,
-                                   uint32_t order, uint32_t xcd, bool nontemporal, uint32_t block_threads,
+                                   uint32_t order, uint32_t xcd, int store_mode, uint32_t block_threads,
                                    hipStream_t stream);
 #define BF_PROBE_REDUCE_WAVES 8192
 hipError_t bf_launch_probe_reduce(const void *in, size_t bytes, unsigned long long *d_part, hipStream_t stream);
+hipError_t bf_launch_probe_one_store(void *out, size_t bytes, int store_mode, int stores_per_thread, uint32_t row_bytes,
+                                     hipStream_t stream);
 hipError_t bf_warm_module();
 hipError_t bf_launch_verify_div3(float D, float y, uint32_t *d_mismatches, hipStream_t stream);
 

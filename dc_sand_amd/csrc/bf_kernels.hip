@@ -47,6 +47,24 @@ __device__ __forceinline__ void store_global(T *p, const T v)
         *p = v;
 }
 
+// Cache-policy variants of the 16-byte store (probe only): 0 plain, 1 nt, 2 sc1
+// (write-through), 3 sc0 sc1, 4 sc1 nt.
+template <int MODE>
+__device__ __forceinline__ void store16_mode(uintx4 *p, const uintx4 v)
+{
+    if constexpr (MODE == 0) {
+        *p = v;
+    } else if constexpr (MODE == 1) {
+        __builtin_nontemporal_store(v, p);
+    } else if constexpr (MODE == 2) {
+        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+    } else if constexpr (MODE == 3) {
+        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+    } else {
+        asm volatile("global_store_dwordx4 %0, %1, off sc1 nt\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+    }
+}
+
 // (cos, sin) of one coefficient, fast path (bf_math.h; swept exhaustively).
 //   DIV3   : 3-op divide by the launch constant (only when dcs_bf_create has
 //            verified it exact for this D), else the 5-op form
@@ -234,6 +252,7 @@ __global__ void __launch_bounds__(kBlock) bf_tiled_kernel(const bf_tiled_args a)
 #pragma unroll
                 for (int j = 0; j < PPL; j++)
                     coeff_fast<decltype(div3)::value, decltype(lowdeg)::value>(fRate[j], fPhase0[j], fChan, D, y, re[j], im[j]);
+                for (uint32_t k = 0; k < a.pace; k++) __builtin_amdgcn_s_sleep(1); // tuning knob: 64-cycle units before each store
                 emit(re, im);
                 dst += step;
             }
@@ -625,6 +644,38 @@ __global__ void __launch_bounds__(kBlock) bf_probe_sincos_kernel(int which, cons
     c[i] = fc;
 }
 
+// The leanest possible store kernel: one 16-byte store per thread, no loop, no division;
+// SPT > 1: each thread stores SPT times, a workgroup's stores KiB-interleaved over SPT rows
+// `row16` 16-byte units apart (the generator's pattern without its arithmetic).
+template <int MODE, int SPT>
+__global__ void __launch_bounds__(kBlock) bf_probe_one_store_kernel(uintx4 *out, uint32_t row16, uint32_t tiles_per_row)
+{
+    const uintx4 v = {0x3f800000u, blockIdx.x, 0x3f800000u, threadIdx.x};
+    if constexpr (SPT == 1) {
+        store16_mode<MODE>(out + (size_t)blockIdx.x * kBlock + threadIdx.x, v);
+    } else {
+        // workgroup b: tile (b % tiles_per_row) of row band (b / tiles_per_row); 4 waves x SPT rows
+        const uint32_t tile = blockIdx.x % (tiles_per_row & 0xffffu), band = blockIdx.x / (tiles_per_row & 0xffffu);
+        const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+        uintx4 *p = out + ((size_t)band * 4u * SPT + wave) * row16 + (size_t)tile * 64u + lane;
+        const uint32_t pace = tiles_per_row >> 16; // probe: units of 64 cycles slept before each store
+        const uint32_t tiles = tiles_per_row & 0xffffu;
+        (void)tiles;
+        // pace >= 0x8000: instead of sleeping, wait for the wave's previous store to be
+        // acknowledged before issuing the next (at most ONE store in flight per wave)
+        const bool self_paced = (pace & 0x8000u) != 0u;
+#pragma unroll
+        for (int j = 0; j < SPT; j++) {
+            if (self_paced) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            } else {
+                for (uint32_t k = 0; k < pace; k++) __builtin_amdgcn_s_sleep(1);
+            }
+            store16_mode<MODE>(p + (size_t)j * 4u * row16, v);
+        }
+    }
+}
+
 template <bool NT>
 __global__ void __launch_bounds__(kBlock) bf_probe_fill_kernel(uintx4 *out, size_t n16)
 {
@@ -639,7 +690,7 @@ __global__ void __launch_bounds__(kBlock) bf_probe_fill_kernel(uintx4 *out, size
 // col k % QB).  Rectangles are numbered column-fastest (order 0) or row-fastest
 // (order 1); xcd != 0 renumbers workgroups so that those sharing b % 8 (one
 // XCD under round-robin dispatch) own consecutive rectangles.  No arithmetic.
-template <bool NT>
+template <int MODE>
 __global__ void __launch_bounds__(1024) bf_probe_pattern_kernel(uintx4 *out, uint32_t rows, uint32_t cols,
                                                                   uint32_t QB, uint32_t RB, uint32_t order,
                                                                   uint32_t xcd)
@@ -668,7 +719,7 @@ __global__ void __launch_bounds__(1024) bf_probe_pattern_kernel(uintx4 *out, uin
         const uint32_t k = contiguous ? wave * per + j : wave + j * nwaves;
         if (k >= nk) break;
         const uint32_t r = rr * RB + k / QB, q = rq * QB + k % QB;
-        if (r < rows && q < cols) store_global<NT>(out + ((uint64_t)r * cols + q) * 64u + lane, v);
+        if (r < rows && q < cols) store16_mode<MODE>(out + ((uint64_t)r * cols + q) * 64u + lane, v);
     }
 }
 
@@ -816,7 +867,7 @@ hipError_t bf_launch_probe_fill(void *out, size_t bytes, bool nontemporal, hipSt
 }
 
 hipError_t bf_launch_probe_pattern(void *out, uint32_t rows, uint32_t cols, uint32_t QB, uint32_t RB,
-                                   uint32_t order, uint32_t xcd, bool nontemporal, uint32_t block_threads,
+                                   uint32_t order, uint32_t xcd, int store_mode, uint32_t block_threads,
                                    hipStream_t stream)
 {
     if (!rows || !cols || !QB || !RB) return hipErrorInvalidValue;
@@ -824,13 +875,16 @@ hipError_t bf_launch_probe_pattern(void *out, uint32_t rows, uint32_t cols, uint
     if (block_threads % 64u || block_threads > 1024u) return hipErrorInvalidValue;
     const uint64_t nblk = (uint64_t)((cols + QB - 1) / QB) * ((rows + RB - 1) / RB);
     if (nblk > 0x7fffffffull) return hipErrorInvalidValue;
-    const dim3 grid((uint32_t)nblk);
-    if (nontemporal)
-        hipLaunchKernelGGL(bf_probe_pattern_kernel<true>, grid, dim3(block_threads), 0, stream,
-                           reinterpret_cast<uintx4 *>(out), rows, cols, QB, RB, order, xcd);
-    else
-        hipLaunchKernelGGL(bf_probe_pattern_kernel<false>, grid, dim3(block_threads), 0, stream,
-                           reinterpret_cast<uintx4 *>(out), rows, cols, QB, RB, order, xcd);
+    const dim3 grid((uint32_t)nblk), block(block_threads);
+    uintx4 *o = reinterpret_cast<uintx4 *>(out);
+    switch (store_mode) {
+    case 0: hipLaunchKernelGGL(bf_probe_pattern_kernel<0>, grid, block, 0, stream, o, rows, cols, QB, RB, order, xcd); break;
+    case 1: hipLaunchKernelGGL(bf_probe_pattern_kernel<1>, grid, block, 0, stream, o, rows, cols, QB, RB, order, xcd); break;
+    case 2: hipLaunchKernelGGL(bf_probe_pattern_kernel<2>, grid, block, 0, stream, o, rows, cols, QB, RB, order, xcd); break;
+    case 3: hipLaunchKernelGGL(bf_probe_pattern_kernel<3>, grid, block, 0, stream, o, rows, cols, QB, RB, order, xcd); break;
+    case 4: hipLaunchKernelGGL(bf_probe_pattern_kernel<4>, grid, block, 0, stream, o, rows, cols, QB, RB, order, xcd); break;
+    default: return hipErrorInvalidValue;
+    }
     return hipGetLastError();
 }
 
@@ -971,5 +1025,45 @@ hipError_t bf_launch_beamform(const bf_beamform_args &a_in, hipStream_t stream)
         hipLaunchKernelGGL(bf_beamform_kernel<2>, dim3((uint32_t)blocks), dim3(kBlock), lds, stream, a);
     else
         hipLaunchKernelGGL(bf_beamform_kernel<1>, dim3((uint32_t)blocks), dim3(kBlock), lds, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t bf_launch_probe_one_store(void *out, size_t bytes, int store_mode_in, int stores_per_thread, uint32_t row_bytes,
+                                     hipStream_t stream)
+{
+    const int store_mode = store_mode_in & 0xff;
+    const uint32_t pace = (uint32_t)(store_mode_in >> 8) & 0xffffu; // probe: sleep units before each store
+    uintx4 *o = reinterpret_cast<uintx4 *>(out);
+    const size_t n16 = bytes / 16;
+    if (n16 == 0) return hipSuccess;
+    if (stores_per_thread == 1) {
+        const dim3 grid((uint32_t)(n16 / kBlock));
+        if (store_mode == 1)
+            hipLaunchKernelGGL((bf_probe_one_store_kernel<1, 1>), grid, dim3(kBlock), 0, stream, o, 0u, 1u);
+        else
+            hipLaunchKernelGGL((bf_probe_one_store_kernel<0, 1>), grid, dim3(kBlock), 0, stream, o, 0u, 1u);
+        return hipGetLastError();
+    }
+    const uint32_t row16 = row_bytes / 16u, ntiles = row_bytes / 1024u;
+    const uint32_t tiles = ntiles | (pace << 16);
+    const size_t rows = bytes / row_bytes;
+#define DCS_ONE_STORE(SPT)                                                                                   \
+    {                                                                                                        \
+        const dim3 grid((uint32_t)(rows / (4u * SPT) * ntiles));                                             \
+        if (store_mode == 1)                                                                                 \
+            hipLaunchKernelGGL((bf_probe_one_store_kernel<1, SPT>), grid, dim3(kBlock), 0, stream, o, row16, tiles); \
+        else                                                                                                 \
+            hipLaunchKernelGGL((bf_probe_one_store_kernel<0, SPT>), grid, dim3(kBlock), 0, stream, o, row16, tiles); \
+    }
+    switch (stores_per_thread) {
+    case 2: DCS_ONE_STORE(2) break;
+    case 3: DCS_ONE_STORE(3) break;
+    case 4: DCS_ONE_STORE(4) break;
+    case 8: DCS_ONE_STORE(8) break;
+    case 16: DCS_ONE_STORE(16) break;
+    case 64: DCS_ONE_STORE(64) break;
+    default: return hipErrorInvalidValue;
+    }
+#undef DCS_ONE_STORE
     return hipGetLastError();
 }

@@ -197,6 +197,7 @@ struct dcs_bf_tuning {
     int32_t nomath;          /* probe: addressing and stores only */
     int32_t rows_same_tile;  /* form 2: -1 default, 0 = the waves take adjacent tiles, 1 = they share one tile and
                               * interleave rows */
+    int32_t pace;            /* form 1: sleep this many 64-cycle units before each store (0 = none) */
     int32_t math_mode;       /* A/B of the arithmetic forms (all give the same bits): bit 0 = keep the 5-op
                               * divide even where the 3-op form was verified exact for this divisor; bit 1 =
                               * keep the full-degree polynomials even where the low-degree ones are proven */
@@ -246,9 +247,16 @@ int dcs_probe_fill(void *d_out, size_t bytes, int nontemporal, void *stream);
  * patterns the HBM system sustains; profiles/r01_store_patterns.md).  xcd_remap is a
  * bit set: 1 = workgroups sharing blockIdx % 8 take consecutive rectangles, 2 = a wave
  * takes consecutive 1-KiB chunks instead of every n-th, bits 4-6 = rotate the rectangle
- * column within groups of 8 (XCD <-> address affinity probe). */
+ * column within groups of 8 (XCD <-> address affinity probe).  `nontemporal` selects the
+ * store's cache policy: 0 plain, 1 nt, 2 sc1 (write-through), 3 sc0 sc1, 4 sc1 nt. */
 int dcs_probe_store_pattern(void *d_out, uint32_t rows, uint32_t cols_kib, uint32_t qb, uint32_t rb, int order,
                             int xcd_remap, int nontemporal, uint32_t block_threads, void *stream);
+
+/* The leanest store kernels (no loop, no integer division): stores_per_thread = 1 writes
+ * the buffer linearly, one 16-byte store per thread; 2..4 writes it as rows of row_bytes with
+ * the generator's pattern (a 4-wave workgroup = one 1-KiB tile x 4*stores_per_thread rows).
+ * store_mode 0 plain, 1 nontemporal. */
+int dcs_probe_one_store(void *d_out, size_t bytes, int store_mode, int stores_per_thread, uint32_t row_bytes, void *stream);
 
 /* Whole-tensor properties of an fp32 coefficient tensor resident on the device:
  * checksum = sum of its 32-bit words mod 2^64 (order independent), and

@@ -102,6 +102,7 @@ TUNINGS = [
     dict(form=1, tiles_per_block=1, chan_per_block=3),
     dict(form=1, tiles_per_block=4, chan_per_block=1000),
     dict(form=1, tiles_per_block=1, chan_per_block=13, xcd_remap=1),
+    dict(form=1, tiles_per_block=1, chan_per_block=16, pace=3),
     dict(form=2),
     dict(form=2, waves_per_block=4, rows_per_wave=1, rows_same_tile=0),
     dict(form=2, waves_per_block=4, rows_per_wave=2, nontemporal=1, rows_same_tile=0),
