@@ -511,6 +511,7 @@ int launch_rows(dcs_bf_context *c, bool out16, const float *dt_dev, float dt0, u
     const bool ntstore = c->tune.nontemporal < 0 ? true : c->tune.nontemporal != 0;
     const bool xcd = c->tune.xcd_remap < 0 ? !same_tile : c->tune.xcd_remap != 0;
     a.same_tile = same_tile ? 1u : 0u;
+    a.pace = (uint32_t)c->tune.pace;
     return (int)bf_launch_rows(a, out16, nw, rpw, ntstore, xcd, c->tune.nomath != 0, stream);
 }
 

@@ -370,6 +370,7 @@ __global__ void __launch_bounds__(NW * 64) bf_rows_kernel(const bf_rows_args a)
                             coeff_fast<decltype(div3)::value, decltype(lowdeg)::value>(fRate[j], fPhase0[j], fChan, D, y, re[j], im[j]);
                         }
                     }
+                    for (uint32_t k = 0; k < a.pace; k++) __builtin_amdgcn_s_sleep(1); // tuning knob, as in the tiled form
                     emit(re, im);
                     dst += row_bytes * row_step;
                 }

@@ -197,7 +197,7 @@ struct dcs_bf_tuning {
     int32_t nomath;          /* probe: addressing and stores only */
     int32_t rows_same_tile;  /* form 2: -1 default, 0 = the waves take adjacent tiles, 1 = they share one tile and
                               * interleave rows */
-    int32_t pace;            /* form 1: sleep this many 64-cycle units before each store (0 = none) */
+    int32_t pace;            /* sleep this many 64-cycle units before each store (0 = none) */
     int32_t math_mode;       /* A/B of the arithmetic forms (all give the same bits): bit 0 = keep the 5-op
                               * divide even where the 3-op form was verified exact for this divisor; bit 1 =
                               * keep the full-degree polynomials even where the low-degree ones are proven */

@@ -1,4 +1,4 @@
-"""Real kernel: explicit pacing (sleep before each store) x channels per workgroup, config 3."""
+"""Rows form (no per-workgroup fp64 set-up): waves per workgroup x rows per wave x pace, config 3."""
 import sys
 from pathlib import Path
 import numpy as np
@@ -13,15 +13,11 @@ nb = gen.output_bytes(1, 1)
 buf = device.mem_alloc(nb)
 for _ in range(15):
     gen.generate(buf, nb, t0=1, nt=1)
-import os
-FINE = os.environ.get('DCS_FINE')
-CPBS = (8, 10, 12, 14, 16, 20) if FINE else (4, 8, 12, 16, 24, 32, 64)
-PACES = tuple(range(0, 21)) if FINE else (0, 2, 4, 8, 12, 16, 24, 32)
-cands = [(cpb, pace) for cpb in CPBS for pace in PACES]
+cands = [(nw, rpw, st, pace) for nw in (4, 8) for rpw in (1, 2, 3, 4) for st in (1,) for pace in (0, 2, 4, 6, 8, 10, 12, 14, 16, 20, 24)]
 res = {c: [] for c in cands}
 for rnd in range(2):
     for c in cands:
-        gen.set_tuning(form=1, tiles_per_block=1, chan_per_block=c[0], nontemporal=1, pace=c[1])
+        gen.set_tuning(form=2, waves_per_block=c[0], rows_per_wave=c[1], rows_same_tile=c[2], xcd_remap=0, nontemporal=1, pace=c[3])
         ts = []
         for _ in range(10):
             e0, e1 = device.Event(), device.Event()
@@ -29,10 +25,5 @@ for rnd in range(2):
             ts.append(e1.elapsed_ms_since(e0))
         res[c].append(float(np.median(ts[5:])))
 rows = sorted(((np.median(v), c) for c, v in res.items()))
-for m, c in rows[:14]:
-    print(f"cpb={c[0]:2d} pace={c[1]:2d}: {m:.4f} ms -> {bp.coeffs_per_time_step() / m / 1e6:.1f} Gcoeff/s ({nb / m / 1e9:.2f} TB/s)")
-print("by cpb (best pace):")
-for cpb in CPBS:
-    b = min(((np.median(res[(cpb, p)]), p) for p in PACES))
-    z = np.median(res[(cpb, 0)])
-    print(f"  cpb={cpb:2d}: pace 0 -> {nb / z / 1e9:.2f} TB/s; best pace {b[1]} -> {nb / b[0] / 1e9:.2f} TB/s")
+for m, c in rows[:12]:
+    print(f"nw={c[0]} rpw={c[1]} same_tile={c[2]} pace={c[3]:2d}: {m:.4f} ms -> {bp.coeffs_per_time_step() / m / 1e6:.1f} Gcoeff/s ({nb / m / 1e9:.2f} TB/s)")
