@@ -56,6 +56,9 @@ def parse():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="nccl = RCCL over xGMI (the product path)")
     ap.add_argument("--shared-device", action="store_true", help="rehearsal: every rank uses GPU 0")
     ap.add_argument("--check-all-ranks", action="store_true", help="every rank spot-checks its slab against the oracle")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="rehearsal on one GPU: run the N > 1 control flow (process group, per-step broadcast on the side "
+                         "stream, double-buffered table, slice gather) with a world of ONE rank over RCCL")
     return ap.parse_args()
 
 
@@ -142,6 +145,11 @@ def pmc_traffic(bytes_algo: int):
 
 def main():
     args = parse()
+    # stdout carries exactly ONE line, the JSON: anything libraries print there on the way
+    # (RCCL's version banner, for one) goes to stderr instead
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -157,10 +165,14 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
-    if N > 1:
+    use_dist = N > 1 or args.force_collective
+    if use_dist:
         import torch.distributed as dist  # noqa: F811
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world <= 1 and "RANK" not in os.environ:  # --force-collective without a launcher
+            os.environ.setdefault("MASTER_PORT", "29531")
+            os.environ["RANK"], os.environ["WORLD_SIZE"] = "0", "1"
         if args.backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         else:
@@ -186,13 +198,13 @@ def main():
     # overlaps this step's generation
     table_host = simulate_input(bp_global) if rank == 0 else np.zeros(bp_global.n_pairs, dtype=delay_vals_dtype)
     tbl = [torch.from_numpy(table_host.view(np.uint8).copy()).cuda() for _ in range(2)]
-    comm_stream = torch.cuda.Stream() if N > 1 else None
+    comm_stream = torch.cuda.Stream() if use_dist else None
     ready = [torch.cuda.Event() for _ in range(2)]
     freed = [torch.cuda.Event() for _ in range(2)]
 
     def prefetch(k: int):
         """Broadcast step k's table into buffer k % 2 on the comm stream."""
-        if N == 1:
+        if not use_dist:
             return
         b = k % 2
         with torch.cuda.stream(comm_stream):
@@ -202,11 +214,11 @@ def main():
 
     def step(k: int):
         b = k % 2
-        if N > 1:
+        if use_dist:
             main_stream.wait_event(ready[b])
         gen.set_delays_from_global(tbl[b].data_ptr(), B_total, beam_off, stream=sh)
         freed[b].record(main_stream)
-        if N > 1:
+        if use_dist:
             prefetch(k + 1)
         gen.generate(out.data_ptr(), out_bytes, t0=1 + (k % 255), nt=1, stream=sh)
 
@@ -224,15 +236,24 @@ def main():
         tuning = gen.autotune(out.data_ptr(), out_bytes, stream=sh)
         torch.cuda.synchronize()
 
+    if use_dist:
+        # untimed set-up: the first barrier / all-reduce of a process group sets up its
+        # channels (tens of ms with the GPU idle); do that here, not between warm-up and timing
+        dist.barrier()
+        dist.all_reduce(torch.zeros(1, dtype=torch.float64, device="cuda"), op=dist.ReduceOp.MAX)
+        torch.cuda.synchronize()
     for b in range(2):
         freed[b].record(main_stream)
     prefetch(0)
     for k in range(args.warmup):
         step(k)
     torch.cuda.synchronize()
-    if N > 1:
+    t_bar = time.perf_counter()
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
+    if use_dist and rank == 0:
+        print(f"barrier before the timed region: {(time.perf_counter() - t_bar) * 1e3:.3f} ms", file=sys.stderr)
 
     e0, e1 = device.Event(), device.Event()
     marks = [device.Event() for _ in range(args.steps)]  # one per step: the distribution, not only the mean
@@ -243,13 +264,13 @@ def main():
         marks[i].record(sh)
     e1.record(sh)
     torch.cuda.synchronize()
-    if N > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t_start
     ev_ms = e1.elapsed_ms_since(e0)
 
-    if N > 1:
+    if use_dist:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -285,6 +306,8 @@ def main():
         # 16-KiB-per-row slice gather is the only other kernel there)
         kern_ms = ev_ms / args.steps
         per_step = np.diff([0.0] + [m.elapsed_ms_since(e0) for m in marks])
+        if os.environ.get("DCS_BENCH_DUMP_STEPS"):
+            print("per-step ms:", " ".join(f"{x:.3f}" for x in per_step), file=sys.stderr)
         algo_bytes = 8 * coeffs_per_gpu_step
         achieved = algo_bytes / (kern_ms * 1e-3) / 1e9
         result = {
@@ -302,13 +325,13 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": f"{args.ant}ant x {B_total}beam x {args.chan}chan, 1 time step per step, "
-                            f"beam-sharded {args.beams_per_gpu} beams/GPU" + (f", {args.backend} bcast of the delay table each step" if N > 1 else ""),
+                            f"beam-sharded {args.beams_per_gpu} beams/GPU" + (f", {args.backend} bcast of the delay table each step" if use_dist else ""),
                 "coeffs_per_step": coeffs_per_gpu_step * N,
                 "output_bytes_per_gpu_step": out_bytes,
                 "kernel": "MULTIPLE_CHANNELS_AND_TIMESTAMPS (tiled form)",
                 "launch_geometry": ({k: tuning[k] for k in ("tiles_per_block", "chan_per_block", "nontemporal")} if tuning
                                     else "library defaults"),
-                "collective": ("none" if N == 1 else ("RCCL broadcast" if args.backend == "nccl" else "gloo broadcast (REHEARSAL, not a result)")),
+                "collective": ("none" if not use_dist else ("RCCL broadcast" if args.backend == "nccl" else "gloo broadcast (REHEARSAL, not a result)")),
             },
             "roofline": {
                 "bound": "hbm",
@@ -334,10 +357,11 @@ def main():
             result["cpu_baseline"]["gpu_vs_oracle_spot_check"] = {"max_ulp": check[0], "over_1ulp": check[1],
                                                                   "sample": "first 4 channels of the last timed step"}
             assert check[1] == 0, "GPU output of the timed region differs from the oracle by more than 1 ULP"
-        print(json.dumps(result), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(result) + "\n").encode())
 
     gen.close()
-    if N > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
