@@ -251,7 +251,7 @@ DCS_HD void dcs_sincos_fast(const float x, float *fSin, float *fCos)
     const uint32_t t30 = q << 30, t31 = q << 31;           // bit 1 / bit 0 moved to the sign position
     const bool swap = (int32_t)t31 < 0;
     const uint32_t us = dcs_f32_bits(swap ? cr : sr);
-    const uint32_t uc = dcs_f32_bits(swap ? sr : cr) ^ t31;
+    const uint32_t uc = dcs_f32_bits(swap ? -sr : cr);     // one v_cndmask with a neg modifier (sign flip == xor t31)
     *fSin = dcs_bits_f32(dcs_xor_sign_of(us, t30));
     *fCos = dcs_bits_f32(dcs_xor_sign_of(uc, t30));
 }
