@@ -528,17 +528,10 @@ __global__ void __launch_bounds__(kBlock) bf_beamform_kernel(const bf_beamform_a
             if (!slow) {
                 dispatch_fast(a.k.uDiv3Exact != 0u, !high, [&](auto div3, auto lowdeg) {
                     // terms of antenna al+2 are requested while al is computed (L2 latency >> one step)
-                    constexpr uint32_t kAhead = 2;
-                    floatx2 q[kAhead];
-#pragma unroll
-                    for (uint32_t i = 0; i < kAhead; i++)
-                        q[i] = *reinterpret_cast<const floatx2 *>(tp + 2u * (uint64_t)(a0 + min(i, na - 1u)) * a.B);
-#pragma unroll 2
-                    for (uint32_t al = 0; al < na; al++) {
-                        const floatx2 kp = q[0];
-#pragma unroll
-                        for (uint32_t i = 0; i + 1 < kAhead; i++) q[i] = q[i + 1];
-                        q[kAhead - 1] = *reinterpret_cast<const floatx2 *>(tp + 2u * (uint64_t)(a0 + min(al + kAhead, na - 1u)) * a.B);
+                    auto terms_of = [&](uint32_t al) {
+                        return *reinterpret_cast<const floatx2 *>(tp + 2u * (uint64_t)(a0 + min(al, na - 1u)) * a.B);
+                    };
+                    auto products = [&](uint32_t al, const floatx2 kp) {
 #pragma unroll
                         for (int h = 0; h < CH; h++) {
                             float re, im, sre, sim;
@@ -548,7 +541,21 @@ __global__ void __launch_bounds__(kBlock) bf_beamform_kernel(const bf_beamform_a
                             acc_re[h] = acc_re[h] + pr;
                             acc_im[h] = acc_im[h] + pi;
                         }
+                    };
+                    // three registers in rotation: step al uses one while al+2 is loaded into the one
+                    // step al-1 has just finished with
+                    floatx2 qa = terms_of(0), qb = terms_of(1), qc;
+                    uint32_t al = 0;
+                    for (; al + 2 < na; al += 3) {
+                        qc = terms_of(al + 2);
+                        products(al, qa);
+                        qa = terms_of(al + 3);
+                        products(al + 1, qb);
+                        qb = terms_of(al + 4);
+                        products(al + 2, qc);
                     }
+                    if (al < na) products(al, qa);
+                    if (al + 1 < na) products(al + 1, qb);
                 });
             } else {
                 for (uint32_t al = 0; al < na; al++) {
