@@ -329,7 +329,7 @@ def main():
                 "coeffs_per_step": coeffs_per_gpu_step * N,
                 "output_bytes_per_gpu_step": out_bytes,
                 "kernel": "MULTIPLE_CHANNELS_AND_TIMESTAMPS (tiled form)",
-                "launch_geometry": ({k: tuning[k] for k in ("tiles_per_block", "chan_per_block", "nontemporal")} if tuning
+                "launch_geometry": ({k: tuning[k] for k in ("tiles_per_block", "chan_per_block", "nontemporal", "wg_per_cu")} if tuning
                                     else "library defaults"),
                 "collective": ("none" if not use_dist else ("RCCL broadcast" if args.backend == "nccl" else "gloo broadcast (REHEARSAL, not a result)")),
             },

@@ -31,6 +31,7 @@ struct bf_tiled_args {
 struct bf_kernel_launch {
     const void *func; // nullptr: nothing to launch (empty shape)
     dim3 grid, block;
+    uint32_t shared; // dynamic LDS bytes requested (occupancy limiter; the kernel does not use them)
     bf_tiled_args args;
 };
 hipError_t bf_prepare_tiled(const bf_tiled_args &a, bool out16, int tiles_per_block, bool nontemporal,

@@ -818,6 +818,7 @@ hipError_t bf_prepare_tiled(const bf_tiled_args &a_in, bool out16, int tiles_per
     out->func = fn;
     out->grid = dim3((uint32_t)blocks);
     out->block = dim3(kBlock);
+    out->shared = 0;
     out->args = a;
     return hipSuccess;
 }
@@ -829,7 +830,7 @@ hipError_t bf_launch_tiled(const bf_tiled_args &a, bool out16, int tiles_per_blo
     hipError_t e = bf_prepare_tiled(a, out16, tiles_per_block, nontemporal, &l);
     if (e != hipSuccess || l.func == nullptr) return e;
     void *params[] = {&l.args};
-    return hipLaunchKernel(l.func, l.grid, l.block, params, 0, stream);
+    return hipLaunchKernel(l.func, l.grid, l.block, params, l.shared, stream);
 }
 
 hipError_t bf_launch_naive(const bf_naive_args &a, hipStream_t stream)

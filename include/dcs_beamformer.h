@@ -201,6 +201,9 @@ struct dcs_bf_tuning {
     int32_t math_mode;       /* A/B of the arithmetic forms (all give the same bits): bit 0 = keep the 5-op
                               * divide even where the 3-op form was verified exact for this divisor; bit 1 =
                               * keep the full-degree polynomials even where the low-degree ones are proven */
+    int32_t wg_per_cu;       /* form 1: 0 = default (fp32: 6), -1 = no limit, 2..7 = at most this many workgroups resident per CU (the launch
+                              * asks for unused dynamic LDS to that end): fewer waves in flight keep the store stream
+                              * closer to address order (profiles/r01_store_patterns.md, "Fewer workgroups in flight") */
 };
 int dcs_bf_set_tuning(dcs_bf_context *ctx, const struct dcs_bf_tuning *t);
 
@@ -208,7 +211,7 @@ int dcs_bf_set_tuning(dcs_bf_context *ctx, const struct dcs_bf_tuning *t);
  * delay table currently set) and keep the fastest: the optimum is sharp and moves with
  * shape and arithmetic form (profiles/r01_geometry_sweep.md).  Generates channels
  * [0, min(nr_channels, out_bytes / row)) of time index 1 into d_out repeatedly
- * (14 trial geometries x 2 rounds; each trial first settles ~20 ms on its own geometry, because the
+ * (23 trial geometries x 2 rounds; each trial first settles ~20 ms on its own geometry, because the
  * first launches after a change of access pattern run slower, then times ~3 ms: < 1 s in all);
  * blocks on events, so it cannot be captured in a graph.  The chosen
  * knobs are written to *chosen (may be NULL) and stay in effect for this context.

@@ -22,12 +22,12 @@ for name, A, B, C, nt in (("cfg2 64x64x4096", 64, 64, 4096, 1), ("mid 64x256x819
     chosen = g.autotune(buf, nb)
     a_ms, _ = timeit(lambda: g.generate(buf, nb, t0=1, nt=nt), warm=12, reps=9)
     best = (1e9, None)
-    for tpb in (1, 2, 4):
+    for tpb, wpc in ((1, -1), (1, 7), (1, 6), (1, 5), (2, -1), (4, -1)):
         for cpb in (4, 8, 10, 11, 12, 13, 14, 15, 16, 18, 20, 24, 32):
-            g.set_tuning(form=1, tiles_per_block=tpb, chan_per_block=cpb, nontemporal=1)
+            g.set_tuning(form=1, tiles_per_block=tpb, chan_per_block=cpb, nontemporal=1, wg_per_cu=wpc)
             ms, _ = timeit(lambda: g.generate(buf, nb, t0=1, nt=nt), warm=10, reps=7)
             if ms < best[0]:
-                best = (ms, (tpb, cpb))
-    print(f"{name}: default {n / d_ms / 1e6:.1f}  autotuned {n / a_ms / 1e6:.1f} (tpb={chosen['tiles_per_block']} cpb={chosen['chan_per_block']})  "
+                best = (ms, (tpb, cpb, wpc))
+    print(f"{name}: default {n / d_ms / 1e6:.1f}  autotuned {n / a_ms / 1e6:.1f} (tpb={chosen['tiles_per_block']} cpb={chosen['chan_per_block']} wg_per_cu={chosen['wg_per_cu']})  "
           f"sweep best {n / best[0] / 1e6:.1f} {best[1]}  Gcoeff/s", flush=True)
     g.close(); buf.free()
