@@ -533,6 +533,10 @@ int launch_rows(dcs_bf_context *c, bool out16, const float *dt_dev, float dt0, u
     const bool xcd = c->tune.xcd_remap < 0 ? !same_tile : c->tune.xcd_remap != 0;
     a.same_tile = same_tile ? 1u : 0u;
     a.pace = (uint32_t)c->tune.pace;
+    if (c->tune.wg_per_cu > 0) { // rows form: only when asked for (no default limit)
+        uint32_t per = (160u * 1024u / (uint32_t)c->tune.wg_per_cu) & ~1023u;
+        a.lds_pad = per > 64u * 1024u ? 64u * 1024u : per;
+    }
     return (int)bf_launch_rows(a, out16, nw, rpw, ntstore, xcd, c->tune.nomath != 0, stream);
 }
 

@@ -65,6 +65,7 @@ struct bf_rows_args {
     uint32_t div3; // dcs_bf_consts::uDiv3Exact
     uint32_t same_tile; // the workgroup's waves share one tile and interleave rows
     uint32_t pace;      // 64-cycle sleeps before each store (tuning knob)
+    uint32_t lds_pad;   // host only: dynamic LDS the launch asks for (occupancy limiter, unused by the kernel)
     float D, y;
 };
 hipError_t bf_launch_rows(const bf_rows_args &a, bool out16, int waves_per_block, int rows_per_wave,

@@ -903,7 +903,7 @@ template <bool OUT16, int NW, int RPW>
 hipError_t launch_rows_t(const bf_rows_args &a, bool nt, bool aligned, bool nomath, dim3 grid, hipStream_t stream)
 {
 #define DCS_ROWS_LAUNCH(NTV, ALV, NMV)                                                                       \
-    hipLaunchKernelGGL((bf_rows_kernel<OUT16, NW, RPW, NTV, ALV, NMV>), grid, dim3(NW * 64), 0, stream, a)
+    hipLaunchKernelGGL((bf_rows_kernel<OUT16, NW, RPW, NTV, ALV, NMV>), grid, dim3(NW * 64), a.lds_pad, stream, a)
     if (nomath) {
         if (nt) { if (aligned) DCS_ROWS_LAUNCH(true, true, true); else DCS_ROWS_LAUNCH(true, false, true); }
         else    { if (aligned) DCS_ROWS_LAUNCH(false, true, true); else DCS_ROWS_LAUNCH(false, false, true); }

@@ -103,6 +103,9 @@ TUNINGS = [
     dict(form=1, tiles_per_block=4, chan_per_block=1000),
     dict(form=1, tiles_per_block=1, chan_per_block=13, xcd_remap=1),
     dict(form=1, tiles_per_block=1, chan_per_block=16, pace=3),
+    dict(form=1, tiles_per_block=1, chan_per_block=12, wg_per_cu=-1),
+    dict(form=1, tiles_per_block=2, chan_per_block=5, wg_per_cu=2),
+    dict(form=1, tiles_per_block=4, chan_per_block=9, wg_per_cu=7),
     dict(form=2),
     dict(form=2, waves_per_block=4, rows_per_wave=1, rows_same_tile=0),
     dict(form=2, waves_per_block=4, rows_per_wave=2, nontemporal=1, rows_same_tile=0),
@@ -110,6 +113,7 @@ TUNINGS = [
     dict(form=2, waves_per_block=16, rows_per_wave=1, xcd_remap=1, nontemporal=1, rows_same_tile=0),
     dict(form=2, waves_per_block=16, rows_per_wave=4, rows_same_tile=0),
     dict(form=2, waves_per_block=4, rows_per_wave=3, rows_same_tile=1),
+    dict(form=2, waves_per_block=4, rows_per_wave=3, rows_same_tile=1, wg_per_cu=4),
     dict(form=2, waves_per_block=8, rows_per_wave=1, rows_same_tile=1, xcd_remap=0),
 ]
 
@@ -226,6 +230,10 @@ def test_error_behaviour(gpu):
     with pytest.raises(_lib.DcsError) as e:
         g.generate(buf, buf.nbytes - 1)
     assert e.value.status == _lib.DCS_ERR_INVALID_ARGUMENT
+    for bad in (dict(wg_per_cu=1), dict(wg_per_cu=8), dict(wg_per_cu=-2), dict(tiles_per_block=3), dict(form=3), dict(pace=-1)):
+        with pytest.raises(_lib.DcsError) as e:
+            g.set_tuning(**bad)
+        assert e.value.status == _lib.DCS_ERR_INVALID_ARGUMENT, bad
     g.close()
 
 
