@@ -84,8 +84,8 @@ geometry {b['config']['launch_geometry']}: {vg['VGPR_Count']} VGPRs, {vg['LDS_Bl
 bench.py first lets the library measure its launch geometry (untimed; separate kernel symbols), then runs 24 plain fills of the output buffer
 (`__amd_rocclr_fillBufferAligned`, ~2.8 ms each = 6.1 TB/s) to bring the device out of idle; the first few generator launches are
 still 3-10 % slower than steady state and fall in the W = 10 warm-up steps.  The event-based `kernel_ms`, the per-dispatch
-trace of the same launches and the `--stats` average agree within 0.5 %.  HBM traffic equals the algorithmic bytes: every store is a whole-line write,
-nothing is re-read.  Box-to-box spread seen this round for the same binary: 880-905 Gcoeff/s.
+trace of the same launches and the `--stats` average agree within 1 % (the event span also holds the 5-us slice gather and the gaps between launches, which grow a little under the profiler).  HBM traffic equals the algorithmic bytes: every store is a whole-line write,
+nothing is re-read.  Box-to-box spread seen this round: 870-925 Gcoeff/s.
 """
 open(R + f"profiles/{rnd}_bench_profile.md", "w").write(md)
 print(md[md.index("| quantity"):])
