@@ -1,7 +1,7 @@
 /*
  * bf_oracle.c -- CPU restatement of the dc_sand steering-coefficient verifier.
  * TEST INFRASTRUCTURE ONLY (see bf_oracle.h).  "parity unpinned": the reference
- * holds no golden vectors and is unbuildable here (CUDA headers absent).
+ * holds no golden vectors and is unbuildable here (no nvcc, no libcudart).
  *
  * Build: gcc -O2 -ffp-contract=off (no -march=native, no -ffast-math): every
  * fp32 operation below must round once, in the order written, and no
@@ -9,8 +9,20 @@
  *
  * Typing notes (x86-64, FLT_EVAL_METHOD == 0):
  *  - `float * size_t` and `float * int` convert the integer to float.
- *  - `cos(float)` is `double cos(double)`; the result is rounded to float on
- *    assignment ("double-then-round" reading).
+ *  - `cos(float)`: TWO readings, selected by dcs_oracle_set_trig_reading():
+ *      0 (default, canonical for this repo's fixtures): `double cos(double)`, rounded to
+ *        float on assignment -- what the text means under ISO C / plain g++ with <cmath>
+ *        ("double-then-round"); libm-independent to within a
+ *        double's accuracy.
+ *      1: `cosf` / `sinf` of the host's float libm -- what the reference's own toolchain
+ *        binds to: nvcc force-includes cuda_runtime.h in every .cu, whose
+ *        crt/math_functions.h says `using std::cos; using std::sin;` at global scope for
+ *        GCC hosts (CUDA 12.8 headers as shipped in this image under
+ *        triton/backends/nvidia/include/crt/math_functions.h:4838-4862), so the
+ *        unqualified `cos(fRotation)` of BeamformerCoefficientTest.cu:327 resolves to
+ *        libstdc++'s `std::cos(float)` = `__builtin_cosf`.  Its value depends on the glibc
+ *        the reference was linked against (unpinned by the reference; 2.35 here).
+ *    The two differ by exactly 1 ULP in about 1.3 % of samples.
  */
 #define _GNU_SOURCE
 #include "bf_oracle.h"
@@ -103,14 +115,25 @@ float dcs_oracle_rotation(const struct dcs_oracle_params *p,
     return fRotation;
 }
 
+/* Which function the verifier's unqualified cos(float) / sin(float) binds to (header comment). */
+static int g_trig_reading = 0;
+void dcs_oracle_set_trig_reading(int reading) { g_trig_reading = reading == 1 ? 1 : 0; }
+int dcs_oracle_get_trig_reading(void) { return g_trig_reading; }
+
 /* BeamformerCoefficientTest.cu:319-328 */
 void dcs_oracle_coeff(const struct dcs_oracle_params *p,
                       struct dcs_oracle_delay_vals d, float fDeltaTime,
                       size_t c, float *re, float *im)
 {
     float fRotation = dcs_oracle_rotation(p, d, fDeltaTime, c);
-    float fSteeringCoeffCorrectReal = cos(fRotation);
-    float fSteeringCoeffCorrectImag = sin(fRotation);
+    float fSteeringCoeffCorrectReal, fSteeringCoeffCorrectImag;
+    if (g_trig_reading == 1) {
+        fSteeringCoeffCorrectReal = cosf(fRotation);
+        fSteeringCoeffCorrectImag = sinf(fRotation);
+    } else {
+        fSteeringCoeffCorrectReal = cos(fRotation);
+        fSteeringCoeffCorrectImag = sin(fRotation);
+    }
     *re = fSteeringCoeffCorrectReal;
     *im = fSteeringCoeffCorrectImag;
 }

@@ -71,6 +71,11 @@ void dcs_oracle_simulate_input(const struct dcs_oracle_params *p,
                                struct dcs_oracle_delay_vals *out);
 
 /* BeamformerCoefficientTest.cu:319-328 -- one coefficient. */
+/* 0 (default): (float)cos((double)rot); 1: cosf(rot) of the host libm -- see bf_oracle.c.
+ * Process-wide; set it before calling the generate / beamform functions. */
+void dcs_oracle_set_trig_reading(int reading);
+int dcs_oracle_get_trig_reading(void);
+
 void dcs_oracle_coeff(const struct dcs_oracle_params *p,
                       struct dcs_oracle_delay_vals d, float fDeltaTime,
                       size_t c, float *re, float *im);

@@ -3,7 +3,7 @@ reference's CPU verifier) plus an independent numpy restatement of the same
 lines, used to cross-check the C one.  TEST INFRASTRUCTURE ONLY.
 
 PARITY STATUS: "parity unpinned" -- the reference stores no golden vectors for
-this path and cannot be built here (CUDA headers absent); see bf_oracle.h.
+this path and cannot be built here (no nvcc, no libcudart); see bf_oracle.h.
 """
 from __future__ import annotations
 
@@ -78,6 +78,8 @@ def lib() -> ctypes.CDLL:
         L.dcs_oracle_device_variant_a3.argtypes = [P, c_void_p, c_size_t, c_size_t, c_void_p]
         L.dcs_oracle_simulate_antenna_data.argtypes = [c_void_p, c_size_t]
         L.dcs_oracle_beamform.argtypes = [P, c_void_p, c_size_t, c_void_p, c_void_p]
+        L.dcs_oracle_set_trig_reading.argtypes = [c_int]
+        L.dcs_oracle_get_trig_reading.restype = c_int
         L.dcs_oracle_f32_to_f16_rn.argtypes = [c_float]
         L.dcs_oracle_f32_to_f16_rn.restype = c_uint16
         _LIB = L
@@ -109,6 +111,27 @@ def time_step_ns(p: OracleParams, t: int) -> int:
 
 def time_step_ns_launch_loop(p: OracleParams, t: int) -> int:
     return int(lib().dcs_oracle_time_step_ns_launch_loop(byref(p), int(t)))
+
+
+DOUBLE_THEN_ROUND, FLOAT_LIBM = 0, 1
+
+
+class trig_reading:
+    """``with trig_reading(FLOAT_LIBM): ...`` -- evaluate the verifier's ``cos(fRotation)`` as the host
+    libm's ``cosf`` (what nvcc's headers bind it to) instead of ``(float)cos((double)x)`` (the default,
+    canonical reading of this repo's fixtures).  See the header comment of bf_oracle.c."""
+
+    def __init__(self, reading: int):
+        self.reading = int(reading)
+
+    def __enter__(self):
+        self.prev = lib().dcs_oracle_get_trig_reading()
+        lib().dcs_oracle_set_trig_reading(self.reading)
+        return self
+
+    def __exit__(self, *exc):
+        lib().dcs_oracle_set_trig_reading(self.prev)
+        return False
 
 
 def generate(p: OracleParams, delays: np.ndarray, t0=0, nt=1, c0=0, nc=None) -> np.ndarray:

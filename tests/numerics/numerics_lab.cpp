@@ -33,7 +33,21 @@ struct sweep_job {
     uint32_t max_a, max_b;
     uint64_t over_a, over_b;
     uint32_t worst_a, worst_b;
+    /* sincos sweep only: faithfulness (result is one of the two floats bracketing the true
+     * value) and distance to this host's float libm (sinf / cosf) */
+    uint64_t unfaithful_a, unfaithful_b, over_f_a, over_f_b;
+    uint32_t max_f_a, max_f_b;
 };
+
+/* r is RD(t) or RU(t) of the true value, taken from its double evaluation td (2^-53 relative:
+ * ambiguous only if td is within that of a float, where both neighbours are accepted anyway) */
+static inline int faithful(float r, double td)
+{
+    const float f = (float)td;
+    if ((double)f == td) return r == f;
+    const float other = (double)f < td ? nextafterf(f, INFINITY) : nextafterf(f, -INFINITY);
+    return r == f || r == other;
+}
 
 static void *sincos_worker(void *arg)
 {
@@ -51,6 +65,13 @@ static void *sincos_worker(void *arg)
         if (dc > j->max_b) { j->max_b = dc; j->worst_b = u; }
         if (ds > 1) j->over_a++;
         if (dc > 1) j->over_b++;
+        if (!faithful(s, sin((double)x))) j->unfaithful_a++;
+        if (!faithful(c, cos((double)x))) j->unfaithful_b++;
+        const uint32_t fs = ulp_diff(s, sinf(x)), fc = ulp_diff(c, cosf(x));
+        if (fs > j->max_f_a) j->max_f_a = fs;
+        if (fc > j->max_f_b) j->max_f_b = fc;
+        if (fs > 1) j->over_f_a++;
+        if (fc > 1) j->over_f_b++;
     }
     return NULL;
 }
@@ -96,6 +117,12 @@ static void run_sweep(void *(*fn)(void *), struct sweep_job *proto, int nthreads
         if (jobs[i].max_b > out->max_b) { out->max_b = jobs[i].max_b; out->worst_b = jobs[i].worst_b; }
         out->over_a += jobs[i].over_a;
         out->over_b += jobs[i].over_b;
+        out->unfaithful_a += jobs[i].unfaithful_a;
+        out->unfaithful_b += jobs[i].unfaithful_b;
+        out->over_f_a += jobs[i].over_f_a;
+        out->over_f_b += jobs[i].over_f_b;
+        if (jobs[i].max_f_a > out->max_f_a) out->max_f_a = jobs[i].max_f_a;
+        if (jobs[i].max_f_b > out->max_f_b) out->max_f_b = jobs[i].max_f_b;
     }
     free(jobs);
     free(th);
@@ -122,6 +149,19 @@ void lab_sincos_sweep(int lowdeg, uint32_t lo_bits, uint32_t hi_bits, int nthrea
     run_sweep(sincos_worker, &p, nthreads, &o);
     res[0] = o.max_a; res[1] = o.max_b; res[2] = o.over_a; res[3] = o.over_b;
     res[4] = o.worst_a; res[5] = o.worst_b;
+}
+
+/* Same sweep, the two further properties: res = {n_unfaithful_sin, n_unfaithful_cos,
+ * n_sin_over_1_vs_sinf, n_cos_over_1_vs_cosf, max_ulp_vs_sinf, max_ulp_vs_cosf}. */
+void lab_sincos_sweep_faithful(int lowdeg, uint32_t lo_bits, uint32_t hi_bits, int nthreads, uint64_t *res)
+{
+    struct sweep_job p = {}, o;
+    p.lo = lo_bits;
+    p.hi = hi_bits;
+    p.variant = lowdeg;
+    run_sweep(sincos_worker, &p, nthreads, &o);
+    res[0] = o.unfaithful_a; res[1] = o.unfaithful_b; res[2] = o.over_f_a; res[3] = o.over_f_b;
+    res[4] = o.max_f_a; res[5] = o.max_f_b;
 }
 
 /* res = {n_mismatch, max_ulp, first_bad_x_bits, n_signed_zero_diffs} */

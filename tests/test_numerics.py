@@ -26,6 +26,7 @@ def lab():
     assert res.returncode == 0, res.stderr
     L = ctypes.CDLL(str(LAB_DIR / "libnumerics_lab.so"))
     L.lab_sincos_sweep.argtypes = [ctypes.c_int, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int, ctypes.POINTER(ctypes.c_uint64)]
+    L.lab_sincos_sweep_faithful.argtypes = [ctypes.c_int, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int, ctypes.POINTER(ctypes.c_uint64)]
     L.lab_div_sweep.argtypes = [ctypes.c_int, ctypes.c_float, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int, ctypes.POINTER(ctypes.c_uint64)]
     L.lab_sincos.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p]
     L.lab_generate_fast.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int32, ctypes.c_float, ctypes.c_float,
@@ -52,6 +53,29 @@ def test_low_degree_sincos_every_fp32_below_512(lab):
     assert res[2] == 0 and res[3] == 0, f"over 1 ULP: sin {res[2]}, cos {res[3]}"
     lab.lab_sincos_sweep(1, _bits(512.0), _bits(32768.0), 8, res)
     assert res[2] > 0 or res[3] > 0
+
+
+def test_sincos_against_the_host_float_libm_every_fp32(lab):
+    """The other reading of the verifier's ``cos(fRotation)`` (oracle/bf_oracle.c): nvcc's headers bind
+    it to ``cosf`` -- here glibc's.  Every positive fp32 of each polynomial set's range:
+      * low-degree set (every |fRotation| of the wave < 500), [2^-40, 512): within 1 ULP of sinf / cosf
+        for EVERY argument;
+      * full set, [2^-40, 32768): within 2 ULP, and the arguments at 2 ULP are a few dozen out of
+        4.6e8, none below 256 (glibc 2.35: 29 for sin, 35 for cos; the bound leaves room for other
+        glibc versions);
+    and how far the device sequence is from FAITHFUL rounding (result one of the two floats bracketing the
+    true value), which is what would make it within 1 ULP of any faithful libm: about 0.05 % of the
+    arguments are not (their error is between 1 and 1.5 ULP of the true value while still within 1 ULP
+    of the correctly rounded one)."""
+    res = (ctypes.c_uint64 * 6)()
+    lab.lab_sincos_sweep_faithful(1, _bits(2.0 ** -40), _bits(512.0), 8, res)
+    assert res[2] == 0 and res[3] == 0 and res[4] <= 1 and res[5] <= 1, list(res)
+    n_low = _bits(512.0) - _bits(2.0 ** -40)
+    assert res[0] < 1e-3 * n_low and res[1] < 1e-3 * n_low
+    lab.lab_sincos_sweep_faithful(0, _bits(2.0 ** -40), _bits(256.0), 8, res)
+    assert res[2] == 0 and res[3] == 0, list(res)
+    lab.lab_sincos_sweep_faithful(0, _bits(256.0), _bits(32768.0), 8, res)
+    assert res[4] <= 2 and res[5] <= 2 and res[2] < 200 and res[3] < 200, list(res)
 
 
 def test_sincos_symmetry_and_tiny_arguments(lab, oracle):
