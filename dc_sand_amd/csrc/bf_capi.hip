@@ -728,7 +728,7 @@ int dcs_bf_autotune(dcs_bf_context *c, int bitwidth, void *d_out, size_t out_byt
     // ~1 % higher, profiles/r01_store_patterns.md); fp16: VALU-bound, long walks
     static const int k32[][3] = {{1, 8, -1}, {1, 10, -1}, {1, 11, -1}, {1, 12, -1}, {1, 13, -1}, {1, 14, -1}, {1, 15, -1},
                                  {1, 16, -1}, {1, 18, -1}, {1, 20, -1}, {1, 24, -1}, {2, 8, -1}, {2, 12, -1}, {4, 8, -1},
-                                 {1, 10, 7}, {1, 11, 7}, {1, 12, 7}, {1, 11, 6}, {1, 12, 6}, {1, 13, 6}, {1, 14, 6},
+                                 {1, 10, 7}, {1, 11, 7}, {1, 12, 7}, {1, 13, 7}, {1, 14, 7}, {1, 11, 6}, {1, 12, 6}, {1, 13, 6}, {1, 14, 6},
                                  {1, 14, 5}, {1, 16, 5}};
     static const int k16[][3] = {{1, 32, -1}, {1, 64, -1}, {1, 96, -1}, {1, 128, -1}, {1, 192, -1}, {1, 256, -1},
                                  {2, 64, -1}, {4, 32, -1}, {4, 48, -1}};

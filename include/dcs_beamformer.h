@@ -211,7 +211,7 @@ int dcs_bf_set_tuning(dcs_bf_context *ctx, const struct dcs_bf_tuning *t);
  * delay table currently set) and keep the fastest: the optimum is sharp and moves with
  * shape and arithmetic form (profiles/r01_geometry_sweep.md).  Generates channels
  * [0, min(nr_channels, out_bytes / row)) of time index 1 into d_out repeatedly
- * (23 trial geometries x 2 rounds; each trial first settles ~20 ms on its own geometry, because the
+ * (25 trial geometries x 2 rounds; each trial first settles ~20 ms on its own geometry, because the
  * first launches after a change of access pattern run slower, then times ~3 ms: < 1 s in all);
  * blocks on events, so it cannot be captured in a graph.  The chosen
  * knobs are written to *chosen (may be NULL) and stay in effect for this context.

@@ -20,11 +20,12 @@ KS = tuple(int(x) for x in os.environ.get("DCS_KS", "0,7,6,5,4,3").split(","))
 CPBS = tuple(int(x) for x in os.environ.get("DCS_CPBS", "8,10,12,14,16,20,24,32").split(","))
 TPB = int(os.environ.get("DCS_TPB", "1"))
 FORM = int(os.environ.get("DCS_FORM", "1"))
+NT = int(os.environ.get("DCS_NT", "1"))
 res = {}
 for rnd in range(2):
     for k in KS:
         for cpb in CPBS:
-            gen.set_tuning(form=FORM, tiles_per_block=TPB, chan_per_block=cpb, nontemporal=1, wg_per_cu=k if k else -1)
+            gen.set_tuning(form=FORM, tiles_per_block=TPB, chan_per_block=cpb, nontemporal=NT, wg_per_cu=k if k else -1)
             for _ in range(8):
                 gen.generate(buf, nb, t0=1, nt=1)
             ts = []
@@ -33,6 +34,6 @@ for rnd in range(2):
                 e0.record(); gen.generate(buf, nb, t0=1, nt=1); e1.record(); e1.synchronize()
                 ts.append(e1.elapsed_ms_since(e0))
             res.setdefault((k, cpb), []).append(float(np.median(ts)))
-print(f"tpb={TPB} form={FORM}"); print("TB/s; rows = workgroups per CU (0 = unlimited), columns = channels per workgroup " + " ".join(f"{c:5d}" for c in CPBS))
+print(f"tpb={TPB} form={FORM} nontemporal={NT}"); print("TB/s; rows = workgroups per CU (0 = unlimited), columns = channels per workgroup " + " ".join(f"{c:5d}" for c in CPBS))
 for k in KS:
     print(f"k={k}: " + " ".join(f"{nb / float(np.min(res[(k, c)])) / 1e9:5.2f}" for c in CPBS), flush=True)
