@@ -1,0 +1,63 @@
+"""bench.py's output contract on a real GPU: exactly ONE line on stdout, a JSON object with
+the driver's fields plus ``roofline`` (and ``cpu_baseline`` at N = 1), on a small shape so the
+two runs take seconds.  The second run drives the N > 1 control flow (process group, per-step
+broadcast on the side stream, double-buffered table, slice gather) over RCCL with a world of
+one rank -- the only way to exercise it on a one-GPU box."""
+import json
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = Path(__file__).resolve().parent.parent
+SMALL = ["--ant", "16", "--beams-per-gpu", "64", "--chan", "2048", "--steps", "5", "--warmup", "2", "--no-extras"]
+
+
+def _run(extra):
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):  # a plain single-process run
+        env.pop(k, None)
+    env["MASTER_PORT"] = "29577"
+    res = subprocess.run([sys.executable, str(ROOT / "bench.py"), *SMALL, *extra], capture_output=True, text=True, env=env,
+                         timeout=600, cwd=str(ROOT))
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [l for l in res.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, f"stdout must carry exactly one line, got {len(lines)}: {res.stdout[:500]}"
+    return json.loads(lines[0])
+
+
+def _common(d, n_gpus=1):
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert k in d, k
+    assert d["unit"] == "Gcoeff/s" and d["n_gpus"] == n_gpus and d["steps"] == 5 and d["warmup"] == 2
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["dtype"] == "f32" and d["data"] == "synthetic" and "workload" in d["config"]
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert r["traffic"] is None  # PMC traffic is committed for the headline workload only; nothing is invented
+    # value = coefficients of all steps / wall time; the kernel-only rate cannot be lower
+    assert 0 < d["value"] * 8 <= r["achieved"] * 1.001
+
+
+def test_single_gpu_line_with_cpu_baseline():
+    d = _run(["--cpu-seconds", "0.3"])
+    _common(d)
+    assert d["config"]["collective"] == "none"
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] == 1 and c["unit"] == "Gcoeff/s" and c["value"] > 0 and c["sample"]
+    assert c["gpu_vs_oracle_spot_check"]["over_1ulp"] == 0
+
+
+def test_collective_control_flow_over_rccl_world_of_one():
+    d = _run(["--force-collective", "--no-cpu-baseline", "--check-all-ranks"])
+    _common(d)
+    assert d["config"]["collective"] == "RCCL broadcast"
+    assert "cpu_baseline" not in d
