@@ -8,7 +8,7 @@ the 64 ant x 1024 beam x 32768 chan coefficient tensor (16 GiB, fp32 complex)
 per GPU from a delay table already resident in HBM.  With N > 1 (launched by
 ``python -m torch.distributed.run``, one rank per GPU) the BEAM axis is sharded:
 the global table holds 1024*N beams, rank 0 broadcasts it over RCCL every step
-(prefetched on a side stream, double-buffered), each rank gathers its 1024-beam
+(issued asynchronously one step ahead, double-buffered, so it overlaps the generation), each rank gathers its 1024-beam
 slice and generates its own column slab -- no other collective (weak scaling).
 
 Rank 0 prints ONE JSON line.  ``roofline`` prices the dominant kernel against
@@ -47,6 +47,9 @@ def parse():
     ap.add_argument("--chan", type=int, default=CHAN)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the fp16 / fused-beamformer side measurements (N = 1)")
+    ap.add_argument("--per-step-events", action="store_true",
+                    help="record a HIP event after every timed step and report the per-step median / min / max "
+                         "(each event is a marker packet that costs the stream ~6 us, so it is off by default)")
     ap.add_argument("--no-autotune", action="store_true",
                     help="keep the library's default launch geometry instead of letting dcs_bf_autotune measure it in the "
                          "untimed set-up (its trial launches run under separate kernel symbols, template TAG = 1, so a "
@@ -198,29 +201,33 @@ def main():
     # overlaps this step's generation
     table_host = simulate_input(bp_global) if rank == 0 else np.zeros(bp_global.n_pairs, dtype=delay_vals_dtype)
     tbl = [torch.from_numpy(table_host.view(np.uint8).copy()).cuda() for _ in range(2)]
-    comm_stream = torch.cuda.Stream() if use_dist else None
-    ready = [torch.cuda.Event() for _ in range(2)]
-    freed = [torch.cuda.Event() for _ in range(2)]
+
+    works = [None, None]
 
     def prefetch(k: int):
-        """Broadcast step k's table into buffer k % 2 on the comm stream."""
-        if not use_dist:
-            return
-        b = k % 2
-        with torch.cuda.stream(comm_stream):
-            comm_stream.wait_event(freed[b])
-            dist.broadcast(tbl[b], src=0)
-            ready[b].record(comm_stream)
+        """Broadcast step k's table into buffer k % 2, overlapping the generation that is launched next.
+        The collective is issued from the main stream's position (the process group's own stream waits
+        until the main stream has got here, i.e. until the previous reader of this buffer, the slice
+        gather of step k - 2, has run) and is NOT waited for here: step k waits for it.  (A side stream
+        with explicit ready / freed events does the same with more queue packets: 0.3 % slower.)"""
+        if use_dist:
+            works[k % 2] = dist.broadcast(tbl[k % 2], src=0, async_op=True)
 
     def step(k: int):
         b = k % 2
         if use_dist:
-            main_stream.wait_event(ready[b])
+            works[b].wait()  # the main stream waits for the broadcast; the host does not block
         gen.set_delays_from_global(tbl[b].data_ptr(), B_total, beam_off, stream=sh)
-        freed[b].record(main_stream)
-        if use_dist:
-            prefetch(k + 1)
+        prefetch(k + 1)
         gen.generate(out.data_ptr(), out_bytes, t0=1 + (k % 255), nt=1, stream=sh)
+
+    if use_dist:
+        # untimed set-up: the first barrier / all-reduce / broadcast of a process group sets up its
+        # channels (tens of ms with the GPU idle); do that first, not between warm-up and timing
+        dist.barrier()
+        dist.all_reduce(torch.zeros(1, dtype=torch.float64, device="cuda"), op=dist.ReduceOp.MAX)
+        dist.broadcast(tbl[1], src=0)
+        torch.cuda.synchronize()
 
     # bring the device out of idle (clock ramp) with plain fills of the output buffer, so
     # that the W warm-up steps and the timed steps all run the kernel at steady state
@@ -231,19 +238,18 @@ def main():
     # untimed set-up: let the library measure its launch geometries on this device for
     # this shape (dcs_bf_autotune; every geometry gives the same bits)
     tuning = None
+    gen.upload_delays(np.ascontiguousarray(simulate_input(bp)), stream=sh)
     if not args.no_autotune:
-        gen.upload_delays(np.ascontiguousarray(simulate_input(bp)), stream=sh)
         tuning = gen.autotune(out.data_ptr(), out_bytes, stream=sh)
-        torch.cuda.synchronize()
+    # ... and settle on the geometry in use: after idle or a change of access pattern the first
+    # ~20 ms of launches run 3-10 % (at worst 30 %) slower, whatever W the caller asked for
+    one = device.Event().record(sh)
+    gen.generate(out.data_ptr(), out_bytes, t0=1, nt=1, stream=sh)
+    two = device.Event().record(sh)
+    two.synchronize()
+    for _ in range(max(4, min(400, int(40.0 / max(two.elapsed_ms_since(one), 1e-3))))):
+        gen.generate(out.data_ptr(), out_bytes, t0=1, nt=1, stream=sh)
 
-    if use_dist:
-        # untimed set-up: the first barrier / all-reduce of a process group sets up its
-        # channels (tens of ms with the GPU idle); do that here, not between warm-up and timing
-        dist.barrier()
-        dist.all_reduce(torch.zeros(1, dtype=torch.float64, device="cuda"), op=dist.ReduceOp.MAX)
-        torch.cuda.synchronize()
-    for b in range(2):
-        freed[b].record(main_stream)
     prefetch(0)
     for k in range(args.warmup):
         step(k)
@@ -256,14 +262,20 @@ def main():
         print(f"barrier before the timed region: {(time.perf_counter() - t_bar) * 1e3:.3f} ms", file=sys.stderr)
 
     e0, e1 = device.Event(), device.Event()
-    marks = [device.Event() for _ in range(args.steps)]  # one per step: the distribution, not only the mean
+    per_step_events = args.per_step_events or bool(os.environ.get("DCS_BENCH_DUMP_STEPS"))
+    marks = [device.Event() for _ in range(args.steps)] if per_step_events else []  # the distribution, not only the mean
     t_start = time.perf_counter()
     e0.record(sh)
     for i, k in enumerate(range(args.warmup, args.warmup + args.steps)):
         step(k)
-        marks[i].record(sh)
+        if per_step_events:
+            marks[i].record(sh)
     e1.record(sh)
+    t_issued = time.perf_counter()
     torch.cuda.synchronize()
+    if rank == 0 and os.environ.get("DCS_BENCH_DUMP_STEPS"):
+        print(f"host issued the {args.steps} timed steps in {(t_issued - t_start) * 1e3:.2f} ms "
+              f"(GPU finished {(time.perf_counter() - t_start) * 1e3:.2f} ms after the start)", file=sys.stderr)
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
@@ -305,7 +317,7 @@ def main():
         # its own stream over the timed region / launches (one launch per step; the
         # 16-KiB-per-row slice gather is the only other kernel there)
         kern_ms = ev_ms / args.steps
-        per_step = np.diff([0.0] + [m.elapsed_ms_since(e0) for m in marks])
+        per_step = np.diff([0.0] + [m.elapsed_ms_since(e0) for m in marks]) if per_step_events else np.array([kern_ms])
         if os.environ.get("DCS_BENCH_DUMP_STEPS"):
             print("per-step ms:", " ".join(f"{x:.3f}" for x in per_step), file=sys.stderr)
         algo_bytes = 8 * coeffs_per_gpu_step
@@ -341,9 +353,8 @@ def main():
                 "frac": achieved / HBM_PEAK_GBPS,
                 "traffic": pmc_traffic(algo_bytes),
                 "kernel_ms": kern_ms,
-                "kernel_ms_median": float(np.median(per_step)),
-                "kernel_ms_min": float(np.min(per_step)),
-                "kernel_ms_max": float(np.max(per_step)),
+                **({"kernel_ms_median": float(np.median(per_step)), "kernel_ms_min": float(np.min(per_step)),
+                    "kernel_ms_max": float(np.max(per_step))} if per_step_events else {}),
                 "algorithmic_bytes_per_launch": algo_bytes,
             },
         }

@@ -1,7 +1,7 @@
 """bench.py's output contract on a real GPU: exactly ONE line on stdout, a JSON object with
 the driver's fields plus ``roofline`` (and ``cpu_baseline`` at N = 1), on a small shape so the
 two runs take seconds.  The second run drives the N > 1 control flow (process group, per-step
-broadcast on the side stream, double-buffered table, slice gather) over RCCL with a world of
+asynchronous broadcast one step ahead, double-buffered table, slice gather) over RCCL with a world of
 one rank -- the only way to exercise it on a one-GPU box."""
 import json
 import os

@@ -76,7 +76,7 @@ geometry {b['config']['launch_geometry']}: {vg['VGPR_Count']} VGPRs, {vg['LDS_Bl
 | the profiled run (`{rnd}_bench_kernel_stats.csv`): `value`, `ms_per_step`, `kernel_ms` | {prof['value']:.1f} Gcoeff/s, {prof['ms_per_step']:.3f} ms, {prof['roofline']['kernel_ms']:.3f} ms |
 | rocprofv3 kernel trace of that run, the 50 timed launches (last 50 dispatches): mean / median / min / max | {st.mean(timed):.3f} / {st.median(timed):.3f} / {min(timed):.3f} / {max(timed):.3f} ms |
 | same, 10 warm-up + 50 timed launches | {st.mean(d):.4f} ms |
-| rocprofv3 `--stats` AverageNs of the production kernel symbol, all {len(allms)} calls (10 warm-up + 50 timed) | {st.mean(allms):.4f} ms |
+| rocprofv3 `--stats` AverageNs of the production kernel symbol, all {len(allms)} calls (untimed settle launches + 10 warm-up + 50 timed) | {st.mean(allms):.4f} ms |
 | WRITE_SIZE per launch | {res['WRITE_SIZE'][1]:.0f} KiB x 1024 = {w / 1e9:.4f} GB = {w / algo:.5f} x algorithmic ({algo / 1e9:.4f} GB) |
 | FETCH_SIZE per launch | {res['FETCH_SIZE'][1]:.0f} KiB x 1024 x 2 (gfx950 correction) = {fr / 1e6:.2f} MB (the 1 MiB delay table) |
 | CPU baseline in the same bench run (oracle = restated reference verifier) | {cb.get('value', 0) * 1e3:.1f} Mcoeff/s on 1 thread ({cb.get('sample', '')}); {cb.get('all_cores', {}).get('value', 0):.2f} Gcoeff/s on {cb.get('all_cores', {}).get('cores', 0)} threads |
