@@ -373,6 +373,10 @@ def main():
 
     gen.close()
     if use_dist:
+        for w in works:  # the last prefetched broadcast has no consumer
+            if w is not None:
+                w.wait()
+        torch.cuda.synchronize()
         dist.barrier()
         dist.destroy_process_group()
 
