@@ -241,6 +241,9 @@ def main():
     gen.upload_delays(np.ascontiguousarray(simulate_input(bp)), stream=sh)
     if not args.no_autotune:
         tuning = gen.autotune(out.data_ptr(), out_bytes, stream=sh)
+    if use_dist:  # the ranks' tuners take different times: line the ranks up before the last, busy, set-up stage
+        torch.cuda.synchronize()
+        dist.barrier()
     # ... and settle on the geometry in use: after idle or a change of access pattern the first
     # ~20 ms of launches run 3-10 % (at worst 30 %) slower, whatever W the caller asked for
     one = device.Event().record(sh)
