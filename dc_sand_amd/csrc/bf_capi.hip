@@ -762,7 +762,12 @@ int dcs_bf_autotune(dcs_bf_context *c, int bitwidth, void *d_out, size_t out_byt
     const int n_settle = (int)std::fmin(400.0, std::fmax(8.0, std::ceil(20.0 / one)));
     const int n_timed = (int)std::fmin(200.0, std::fmax(4.0, std::ceil(3.0 / one)));
     for (int rnd = 0; rnd < 2 && st == 0; rnd++) {
+        double best_so_far = 1e30;
+        for (int i = 0; i < ncand; i++) best_so_far = std::fmin(best_so_far, cands[i].best_ms);
         for (int i = 0; i < ncand && st == 0; i++) {
+            // second round: only candidates within 4 % of the first round's best (the device also
+            // slows by ~1 % over the first seconds of sustained load, so a short tuner is a better one)
+            if (rnd == 1 && cands[i].best_ms > 1.04 * best_so_far) continue;
             c->tune.form = 1;
             c->tune.tiles_per_block = cands[i].tpb;
             c->tune.chan_per_block = cands[i].cpb;
