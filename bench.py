@@ -193,7 +193,11 @@ def main():
     gen = SteeringCoefficientGenerator(bp)
     out_bytes = gen.output_bytes(1, 1)
     out = torch.empty(out_bytes, dtype=torch.uint8, device="cuda")
-    main_stream = torch.cuda.current_stream()
+    # one explicit non-blocking stream for everything (not the legacy null stream, which synchronises
+    # implicitly with every blocking stream a library may have created); it is also torch's current
+    # stream, so the process group orders its collectives against it
+    main_stream = torch.cuda.Stream()
+    torch.cuda.set_stream(main_stream)
     sh = main_stream.cuda_stream  # hipStream_t the kernels are launched on
 
     # the global delay table: the reference's ramp recipe (simulate_input) over all
