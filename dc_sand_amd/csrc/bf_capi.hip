@@ -446,10 +446,11 @@ uint32_t lds_pad_for(int k, bool out16, int tpb)
 }
 
 int prepare_tiled(dcs_bf_context *c, bool out16, const float *dt_dev, float dt0, uint32_t nt, uint32_t c0,
-                  uint32_t nc, void *d_out, bf_kernel_launch *l)
+                  uint32_t nc, void *d_out, bf_kernel_launch *l, const float *dt_host = nullptr)
 {
     bf_tiled_args a;
     std::memset(&a, 0, sizeof(a));
+    if (dt_host && nt <= kDtInline) std::memcpy(a.dt_inline, dt_host, (size_t)nt * sizeof(float));
     a.delays = c->d_table[c->cur];
     a.out = d_out;
     a.dt_dev = dt_dev;
@@ -473,10 +474,10 @@ int prepare_tiled(dcs_bf_context *c, bool out16, const float *dt_dev, float dt0,
 }
 
 int launch_tiled(dcs_bf_context *c, bool out16, const float *dt_dev, float dt0, uint32_t nt, uint32_t c0,
-                 uint32_t nc, void *d_out, hipStream_t stream)
+                 uint32_t nc, void *d_out, hipStream_t stream, const float *dt_host = nullptr)
 {
     bf_kernel_launch l;
-    int st = prepare_tiled(c, out16, dt_dev, dt0, nt, c0, nc, d_out, &l);
+    int st = prepare_tiled(c, out16, dt_dev, dt0, nt, c0, nc, d_out, &l, dt_host);
     if (st != DCS_OK || l.func == nullptr) return st;
     void *params[] = {&l.args};
     return (int)hipLaunchKernel(l.func, l.grid, l.block, params, l.shared, stream);
@@ -589,6 +590,11 @@ int dcs_bf_generate_slab(dcs_bf_context *c, int bitwidth, uint64_t t0, uint32_t 
             float dt;
             if ((st = dcs_bf_delta_times(&c->p, t0 + done, 1, &dt)) != DCS_OK) return st;
             st = launch_form(c, out16, nullptr, dt, 1, c0, nc, dst, s);
+        } else if ((c->tune.form == 0 || c->tune.form == 1) && n <= kDtInline) {
+            // tiled form, few time steps: their dt values ride in the kernel arguments (no copy in front)
+            float dts[kDtInline];
+            if ((st = dcs_bf_delta_times(&c->p, t0 + done, n, dts)) != DCS_OK) return st;
+            st = launch_tiled(c, out16, nullptr, dts[0], n, c0, nc, dst, s, dts);
         } else {
             const float *dt_dev = nullptr;
             if ((st = stage_dt(c, t0 + done, n, s, &dt_dev)) != DCS_OK) return st;

@@ -24,7 +24,12 @@ struct bf_tiled_args {
     uint32_t xcd_remap;           // workgroups sharing blockIdx % 8 (one XCD) take consecutive (tile, channel block)s
     uint32_t pace;                // 64-cycle sleeps before each store of the fast loop (tuning knob)
     dcs_bf_consts k;
+    // fDeltaTime of up to kDtInline time steps by value (kernel arguments): the reference's default
+    // tensor (256 time steps, 134 MB) is a 22 us kernel, and a pinned->device copy of the dt table in
+    // front of it cost another 9 us.  Used when dt_dev == nullptr and nt > 1; [0] == dt0.
+    float dt_inline[256];
 };
+constexpr uint32_t kDtInline = 256;
 
 // A resolved launch (kernel instantiation, geometry, final arguments): what
 // bf_launch_tiled enqueues, and what a hipGraph kernel node is built from.

@@ -152,7 +152,7 @@ __global__ void __launch_bounds__(kBlock) bf_tiled_kernel(const bf_tiled_args a)
     const uint32_t cb = rest % a.n_cblocks;
     const uint32_t t = rest / a.n_cblocks;
 
-    const float dt = a.dt_dev ? a.dt_dev[t] : a.dt0;
+    const float dt = a.dt_dev ? a.dt_dev[t] : (a.nt > 1 ? a.dt_inline[t] : a.dt0);
     const uint32_t pair_base = tg * (uint32_t)(TPB * TILE);
 
     // ---- stage the channel-independent terms of this workgroup's pairs in LDS
@@ -809,7 +809,7 @@ hipError_t bf_prepare_tiled(const bf_tiled_args &a_in, bool out16, int tiles_per
     a.n_cblocks = (a.nc + a.chan_per_block - 1) / a.chan_per_block;
     const uint64_t blocks = (uint64_t)a.n_tile_groups * a.n_cblocks * a.nt;
     if (blocks == 0 || blocks > 0x7fffffffull) return hipErrorInvalidValue;
-    if (a.dt_dev == nullptr && a.nt != 1) return hipErrorInvalidValue;
+    if (a.dt_dev == nullptr && a.nt > kDtInline) return hipErrorInvalidValue;
     if (blocks % 8u) a.xcd_remap = 0; // the renumbering is a bijection only then
     const bool aligned = (a.n_pairs % ppl) == 0 && (reinterpret_cast<uintptr_t>(a.out) % 16u) == 0;
     const void *fn = out16 ? tiled_fn_o<true>(tiles_per_block, nontemporal, aligned, nomath, tuner)
