@@ -140,6 +140,7 @@ __global__ void __launch_bounds__(kBlock) bf_tiled_kernel(const bf_tiled_args a)
     constexpr int TILE = 64 * PPL;
     constexpr int ROWS = 4 / TPB;
     constexpr uint32_t EB = OUT16 ? 4u : 8u; // bytes per coefficient
+    constexpr int kSlowUnroll = OUT16 ? 1 : PPL; // unrolling of the slow path's pair loop (see there)
 
     __shared__ __attribute__((aligned(16))) float s_terms[TPB * TILE * 2]; // {fRateTerm, fPhase0}
 
@@ -261,7 +262,11 @@ __global__ void __launch_bounds__(kBlock) bf_tiled_kernel(const bf_tiled_args a)
         for (uint32_t c = cbeg + row; c < cend; c += ROWS) {
             const float fChan = (float)(a.c0 + c);
             float re[PPL], im[PPL];
-#pragma unroll 1
+            // fp32 (2 pairs per lane): unrolled, so that re[] / im[] stay in registers -- a rolled loop
+            // indexes them dynamically and can put them in scratch (12-20 B per lane: +130-230 us on the
+            // first launch of a process).  fp16 (4 pairs): rolled, four inlined fp64 sincos would cost
+            // the fast loop registers; it has never needed scratch (checked: -Rpass-analysis).
+#pragma unroll kSlowUnroll
             for (int j = 0; j < PPL; j++) coeff_slow(fRate[j], fPhase0[j], fChan, D, re[j], im[j]);
             emit(re, im);
             dst += step;
@@ -558,17 +563,22 @@ __global__ void __launch_bounds__(kBlock) bf_beamform_kernel(const bf_beamform_a
                     if (al + 1 < na) products(al + 1, qb);
                 });
             } else {
-                for (uint32_t al = 0; al < na; al++) {
-                    const floatx2 kp = *reinterpret_cast<const floatx2 *>(tp + 2u * (uint64_t)(a0 + al) * a.B);
-#pragma unroll 1
-                    for (int h = 0; h < CH; h++) {
+                // channel outermost and unrolled (h is a compile-time index: the accumulators stay in
+                // registers, nothing goes to scratch), antennas in order inside -- the same sums
+#pragma unroll
+                for (int h = 0; h < CH; h++) {
+                    float are = acc_re[h], aim = acc_im[h];
+                    for (uint32_t al = 0; al < na; al++) {
+                        const floatx2 kp = *reinterpret_cast<const floatx2 *>(tp + 2u * (uint64_t)(a0 + al) * a.B);
                         float re, im, sre, sim;
                         coeff_slow(kp.x, kp.y, fChan[h], D, re, im);
                         sample(h, al, sre, sim);
                         const float pr = re * sre, pi = im * sim;
-                        acc_re[h] = acc_re[h] + pr;
-                        acc_im[h] = acc_im[h] + pi;
+                        are = are + pr;
+                        aim = aim + pi;
                     }
+                    acc_re[h] = are;
+                    acc_im[h] = aim;
                 }
             }
         }

@@ -115,3 +115,30 @@ def test_invalid_arguments_are_status_codes(dcs_lib):
         h = ctypes.c_void_p()
         assert dcs_lib.dcs_bf_create(byref(good), byref(h)) == _lib.DCS_ERR_NO_DEVICE
         assert not h.value
+
+
+def test_no_kernel_uses_scratch(dcs_lib, tmp_path):
+    """Every kernel of the gfx950 code object has a zero private segment: scratch costs the first launch of
+    a process 130-230 us (the reference's harness times exactly one, cold, launch) and has crept in twice
+    through rolled loops over small per-lane arrays.  Read from the built library's own metadata."""
+    import shutil
+    import subprocess
+
+    from dc_sand_amd import _lib
+
+    llvm = Path("/opt/rocm/lib/llvm/bin")
+    tools = [llvm / "llvm-objcopy", llvm / "clang-offload-bundler", llvm / "llvm-readelf"]
+    if not all(t.exists() for t in tools):
+        tools = [Path(p) for p in (shutil.which("llvm-objcopy"), shutil.which("clang-offload-bundler"), shutil.which("llvm-readelf")) if p]
+    if len(tools) != 3:
+        pytest.skip("LLVM binutils of the ROCm toolchain not found")
+    fat, co = tmp_path / "fatbin.bin", tmp_path / "gfx950.co"
+    subprocess.run([str(tools[0]), f"--dump-section=.hip_fatbin={fat}", str(_lib.LIB_PATH)], check=True, capture_output=True)
+    subprocess.run([str(tools[1]), "--unbundle", "--type=o", f"--input={fat}", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950",
+                    f"--output={co}"], check=True, capture_output=True)
+    notes = subprocess.run([str(tools[2]), "--notes", str(co)], check=True, capture_output=True, text=True).stdout
+    names = [l.split(":", 1)[1].strip() for l in notes.splitlines() if l.strip().startswith(".name:")]
+    sizes = [int(l.split(":", 1)[1]) for l in notes.splitlines() if ".private_segment_fixed_size:" in l]
+    assert len(sizes) > 100, "metadata not found"
+    bad = [(n, s) for n, s in zip([n for n in names if not n.startswith(("a", "_.")) or True][: len(sizes)], sizes) if s != 0]
+    assert not any(s for s in sizes), f"{sum(1 for s in sizes if s)} kernel(s) use scratch: {bad[:3]}"
