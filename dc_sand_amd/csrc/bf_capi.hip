@@ -286,8 +286,6 @@ int dcs_event_elapsed_ms(void *start, void *stop, float *ms)
 }
 
 /* ---- context ------------------------------------------------------------ */
-static int warm_kernels(dcs_bf_context *c); // defined below, next to the launch helpers
-
 int dcs_bf_create(const dcs_bf_params *p, dcs_bf_context **out)
 {
     if (!out) return DCS_ERR_INVALID_ARGUMENT;
@@ -330,7 +328,6 @@ int dcs_bf_create(const dcs_bf_params *p, dcs_bf_context **out)
         if ((st = (int)hipMemcpy(c->d_dt, c->h_dt, sizeof(float), hipMemcpyHostToDevice)) != 0) break;
         if ((st = verify_div3(&c->k)) != 0) break;
         c->div3_verified = c->k.uDiv3Exact;
-        if ((st = warm_kernels(c)) != 0) break;
     } while (0);
     if (st != 0) {
         dcs_bf_destroy(c);
@@ -485,30 +482,6 @@ int launch_tiled(dcs_bf_context *c, bool out16, const float *dt_dev, float dt0, 
     void *params[] = {&l.args};
     return (int)hipLaunchKernel(l.func, l.grid, l.block, params, l.shared, stream);
 }
-
-} // namespace
-
-// The first launch of a kernel symbol in a process costs ~12 us more than the following ones (code
-// not yet resident): the reference's harness times exactly ONE launch (common/UnitTest.cpp:34-53), so
-// the context pays that here, with one channel row of the production fp32 and fp16 kernels into a
-// scratch buffer (zeroed table: every pair is fast-class).  Leaves the context with no table set.
-static int warm_kernels(dcs_bf_context *c)
-{
-    const size_t row = (size_t)c->n_pairs * 8u;
-    if (row > (16u << 20)) return DCS_OK; // not worth a large temporary
-    void *tmp = nullptr;
-    hipError_t e = hipMalloc(&tmp, row);
-    if (e != hipSuccess) return (int)e;
-    int st = (int)hipMemset(c->d_table[0], 0, (size_t)c->n_pairs * sizeof(dcs_delay_vals));
-    c->cur = 0;
-    if (st == 0) st = launch_tiled(c, false, nullptr, 0.0f, 1, 0, 1, tmp, nullptr);
-    if (st == 0) st = launch_tiled(c, true, nullptr, 0.0f, 1, 0, 1, tmp, nullptr);
-    if (st == 0) st = (int)hipDeviceSynchronize();
-    (void)hipFree(tmp);
-    return st;
-}
-
-namespace {
 
 // The terms table (up to 64 MiB) is only needed by the rows form and the fused kernel:
 // allocate it when one of them is first used.  Not capturable (hipMalloc), like those paths.
