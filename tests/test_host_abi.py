@@ -142,3 +142,13 @@ def test_no_kernel_uses_scratch(dcs_lib, tmp_path):
     assert len(sizes) > 100, "metadata not found"
     bad = [(n, s) for n, s in zip([n for n in names if not n.startswith(("a", "_.")) or True][: len(sizes)], sizes) if s != 0]
     assert not any(s for s in sizes), f"{sum(1 for s in sizes if s)} kernel(s) use scratch: {bad[:3]}"
+
+
+def test_makefile_and_build_py_use_the_same_flags():
+    """Two ways to build the library (``make`` / ``python -m dc_sand_amd.build``), one set of flags:
+    -ffp-contract=off and friends are part of the numerical contract."""
+    from dc_sand_amd import build
+
+    mk = (Path(__file__).resolve().parent.parent / "Makefile").read_text()
+    flags = re.search(r"HIPFLAGS := (.*?)\n\n", mk, re.S).group(1).replace("\\\n", " ").split()
+    assert sorted(flags) == sorted(build.flags())
