@@ -747,3 +747,72 @@ def test_config5_streaming_at_the_200us_slab(gpu, oracle):
             assert oracle.max_ulp(host, exp, 1)[1] == 0, (tick, t, cl)
     st.end()
     g.close()
+
+
+def test_seeded_fuzz_of_shapes_slabs_time_ranges_and_geometries(gpu, oracle):
+    """80 seeded random cases: shape (ragged tiles, odd pair counts), channel slab, time range (1..300 time
+    steps: both sides of the 256 that travel in the kernel arguments), kernel selection, output width,
+    launch geometry of either form (incl. wg_per_cu) and an output pointer 0 / 8 / 16 bytes off alignment --
+    every fp32 case within 1 ULP of the oracle, every fp16 case the RN-even image of the fp32 run,
+    canaries before and after the tensor intact."""
+    from dc_sand_amd import BeamformerParameters
+    from dc_sand_amd.generator import SteeringCoefficientGenerator
+
+    rng = np.random.default_rng(20261004)
+    for case in range(80):
+        A, B = int(rng.integers(1, 9)), int(rng.integers(1, 70))
+        C = int(rng.integers(1, 80))
+        nt = int(rng.choice([1, 2, 3, 17, 255, 256, 257, 300])) if case % 4 == 0 else int(rng.integers(1, 6))
+        if nt > 16:
+            A, B, C = min(A, 3), min(B, 9), min(C, 7)  # keep the oracle's work small
+        t0 = int(rng.integers(0, 1000))
+        bp = BeamformerParameters(NR_CHANNELS=C, NR_STATIONS=A, NR_BEAMS=B)
+        table = rand_table(bp.n_pairs, seed=1000 + case)
+        bitwidth = int(rng.integers(0, 2))
+        form = int(rng.integers(1, 3))
+        if form == 1:
+            tuning = dict(form=1, tiles_per_block=int(rng.choice([1, 2, 4])), chan_per_block=int(rng.integers(1, 40)),
+                          nontemporal=int(rng.integers(0, 2)), wg_per_cu=int(rng.choice([-1, 0, 2, 5, 6, 7])))
+        else:
+            tuning = dict(form=2, waves_per_block=int(rng.choice([4, 8, 16])), rows_per_wave=int(rng.integers(1, 5)),
+                          rows_same_tile=int(rng.integers(0, 2)), wg_per_cu=int(rng.choice([0, 3, 6])))
+        use_slab = bool(rng.integers(0, 2))
+        c0 = int(rng.integers(0, C)) if use_slab else 0
+        nc = int(rng.integers(1, C - c0 + 1)) if use_slab else C
+        kernel = 2 if (use_slab or form == 2) else int(rng.choice([1, 2]))
+        eb = 8 if bitwidth == 1 else 4
+        off = int(rng.choice([0, eb, 16]))
+        nbytes = nt * nc * bp.n_pairs * eb
+        g = SteeringCoefficientGenerator(bp)
+        g.set_tuning(**tuning)
+        g.upload_delays(table)
+        buf = gpu.mem_alloc(nbytes + 64)
+        gpu.memset(buf, 0xFF, nbytes + 64)
+        if use_slab:
+            g.generate_slab(int(buf) + off, nbytes, c0, nc, t0=t0, nt=nt, bitwidth=bitwidth)
+        else:
+            g.generate(int(buf) + off, nbytes, t0=t0, nt=nt, kernel=kernel, bitwidth=bitwidth)
+        host = np.empty(nbytes + 64, dtype=np.uint8)
+        gpu.memcpy_dtoh(host, buf)
+        tag = f"case {case}: {A}x{B}x{C} nt={nt} t0={t0} slab=({c0},{nc}) kernel={kernel} b{bitwidth} off={off} {tuning}"
+        assert np.all(host[:off] == 0xFF) and np.all(host[off + nbytes:] == 0xFF), tag
+        exp = oracle.generate(oracle.params_from(bp), table, t0, nt, c0, nc)
+        if bitwidth == 1:
+            got = host[off:off + nbytes].copy().view(np.float32).reshape(exp.shape)
+            mx, n_over, first = oracle.max_ulp(got, exp, 1)
+            assert n_over == 0, f"{tag}: max ULP {mx}, first {first}"
+        else:
+            got16 = host[off:off + nbytes].copy().view(np.uint16)
+            g.set_tuning()
+            buf32 = gpu.mem_alloc(nbytes * 2)
+            if use_slab:
+                g.generate_slab(buf32, nbytes * 2, c0, nc, t0=t0, nt=nt, bitwidth=1)
+            else:
+                g.generate(buf32, nbytes * 2, t0=t0, nt=nt, kernel=2, bitwidth=1)
+            h32 = np.empty(nbytes * 2, dtype=np.uint8)
+            gpu.memcpy_dtoh(h32, buf32)
+            ref16 = oracle.f32_to_f16_bits(h32.view(np.float32))
+            assert np.array_equal(got16, ref16.ravel()), tag
+            buf32.free()
+        g.close()
+        buf.free()
