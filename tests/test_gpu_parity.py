@@ -445,7 +445,9 @@ def test_streaming_graph_ticks_with_table_updates(gpu, oracle):
 
 
 @pytest.mark.parametrize("A,B,C,nt,seeded", [(64, 16, 64, 256, False), (64, 16, 64, 32, True), (8, 4, 5, 16, True),
-                                             (37, 21, 9, 48, True), (130, 3, 4, 16, True), (4, 40, 7, 32, True)])
+                                             (37, 21, 9, 48, True), (130, 3, 4, 16, True), (4, 40, 7, 32, True),
+                                             (9, 5, 3, 16, True), (129, 2, 2, 16, True), (258, 2, 5, 16, True),
+                                             (1, 1, 1, 16, True), (3, 17, 2, 32, True)])
 def test_fused_coefficient_generation_and_beamforming(gpu, oracle, A, B, C, nt, seeded):
     """beams = sum over antennas (in order) of the element-wise product of
     coefficient and int8 sample, against the verifier restatement
@@ -512,6 +514,35 @@ def test_fused_harness_and_slow_path(gpu, oracle):
     got = np.empty_like(exp)
     gpu.memcpy_dtoh(got, d_beams)
     assert np.abs(got - exp).max() <= 2e-4 * 9
+    g.close()
+
+
+@pytest.mark.parametrize("A,B,C", [(9, 16, 16384), (130, 16, 4096)])
+def test_fused_slow_path_with_several_channels_per_pass(gpu, oracle, A, B, C):
+    """The fused kernel's slow branch when a pass covers 4 channels (<= 64 antennas) or 2 (more: the
+    antennas also cross the 128-antenna LDS chunk): enough channels that the launcher keeps 8 per
+    workgroup, and slow-class pairs so that every 16-sample block takes the branch."""
+    from dc_sand_amd import BeamformerParameters
+    from dc_sand_amd.generator import SteeringCoefficientGenerator
+
+    nt = 16
+    bp = BeamformerParameters(NR_CHANNELS=C, NR_STATIONS=A, NR_BEAMS=B, NR_SAMPLES_PER_CHANNEL=nt)
+    op = oracle.params_from(bp)
+    table = rand_table(bp.n_pairs, seed=A)
+    table["fDelayRate_sps"][5] = 1e-2    # |fRotation| far beyond the fast path's range
+    table["fDelayRate_sps"][A + 1] = 1e-30  # rate term outside the divide's proven range
+    ant = np.random.default_rng(A).integers(-128, 128, size=(C, nt // 16, A, 16, 2), dtype=np.int8)
+    exp = oracle.beamform(op, table, nt, ant)
+    g = SteeringCoefficientGenerator(bp)
+    g.upload_delays(table)
+    d_ant = gpu.mem_alloc(ant.nbytes)
+    gpu.memcpy_htod(d_ant, ant)
+    d_beams = gpu.mem_alloc(exp.nbytes)
+    g.generate_and_beamform(d_ant, ant.nbytes, d_beams, exp.nbytes, t0=0, nt=nt)
+    got = np.empty_like(exp)
+    gpu.memcpy_dtoh(got, d_beams)
+    assert np.all(np.isfinite(got))
+    assert np.abs(got - exp).max() <= 2e-4 * A
     g.close()
 
 
