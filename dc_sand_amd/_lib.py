@@ -22,6 +22,7 @@ DCS_ERR_UNSUPPORTED = -2
 DCS_ERR_NOT_READY = -3
 DCS_ERR_OUT_OF_RANGE = -4
 DCS_ERR_NO_DEVICE = -5
+DCS_ERR_WRONG_DEVICE = -6
 
 # enum dcs_bf_kernel / dcs_bf_bitwidth
 NAIVE = 0

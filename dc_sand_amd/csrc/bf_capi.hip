@@ -28,6 +28,13 @@ constexpr int kDtSlots = 8;
 
 inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 
+// A context's buffers and launches belong to the device that was current at dcs_bf_create.
+#define DCS_CHECK_DEVICE(c)                                                \
+    do {                                                                   \
+        int _cur = -1;                                                     \
+        if (hipGetDevice(&_cur) != hipSuccess || _cur != (c)->device) return DCS_ERR_WRONG_DEVICE; \
+    } while (0)
+
 bool params_ok(const dcs_bf_params *p)
 {
     if (!p) return false;
@@ -126,6 +133,7 @@ const char *dcs_error_string(int status)
     case DCS_ERR_NOT_READY: return "dcs error: not ready (no delay table set)";
     case DCS_ERR_OUT_OF_RANGE: return "dcs error: out of range";
     case DCS_ERR_NO_DEVICE: return "dcs error: no HIP device";
+    case DCS_ERR_WRONG_DEVICE: return "dcs error: the context belongs to another device than the current one (dcs_device_set)";
     default: break;
     }
     if (status > 0) return hipGetErrorString((hipError_t)status);
@@ -355,6 +363,7 @@ int dcs_bf_destroy(dcs_bf_context *c)
 int dcs_bf_upload_delays(dcs_bf_context *c, const dcs_delay_vals *table, void *stream)
 {
     if (!c || !table) return DCS_ERR_INVALID_ARGUMENT;
+    DCS_CHECK_DEVICE(c);
     const int nxt = c->table_set ? (c->cur ^ 1) : c->cur;
     DCS_TRY(hipMemcpyAsync(c->d_table[nxt], table, (size_t)c->n_pairs * sizeof(dcs_delay_vals),
                            hipMemcpyHostToDevice, as_stream(stream)));
@@ -367,6 +376,7 @@ int dcs_bf_set_delays_from_global(dcs_bf_context *c, const void *d_global, uint3
                                   uint32_t beam_offset, void *stream)
 {
     if (!c || !d_global) return DCS_ERR_INVALID_ARGUMENT;
+    DCS_CHECK_DEVICE(c);
     if ((uint64_t)beam_offset + (uint64_t)c->p.nr_beams > nb_total) return DCS_ERR_OUT_OF_RANGE;
     if ((reinterpret_cast<uintptr_t>(d_global) & 15u) != 0) return DCS_ERR_INVALID_ARGUMENT;
     const int nxt = c->table_set ? (c->cur ^ 1) : c->cur;
@@ -573,6 +583,7 @@ int dcs_bf_generate_slab(dcs_bf_context *c, int bitwidth, uint64_t t0, uint32_t 
                          void *d_out, size_t out_bytes, void *stream)
 {
     if (!c || (!d_out && nt && nc)) return DCS_ERR_INVALID_ARGUMENT;
+    DCS_CHECK_DEVICE(c);
     if (bitwidth != DCS_BF_B16 && bitwidth != DCS_BF_B32) return DCS_ERR_INVALID_ARGUMENT;
     if (!c->table_set) return DCS_ERR_NOT_READY;
     if ((uint64_t)c0 + nc > (uint64_t)c->p.nr_channels) return DCS_ERR_OUT_OF_RANGE;
@@ -610,6 +621,7 @@ int dcs_bf_generate(dcs_bf_context *c, int kernel, int bitwidth, uint64_t t0, ui
                     size_t out_bytes, void *stream)
 {
     if (!c) return DCS_ERR_INVALID_ARGUMENT;
+    DCS_CHECK_DEVICE(c);
     if (bitwidth != DCS_BF_B16 && bitwidth != DCS_BF_B32) return DCS_ERR_INVALID_ARGUMENT;
     // BeamformerCoefficientTest.cu:40-50 (the reference throws)
     if (kernel == DCS_BF_COMBINED_COEFF_GEN_AND_BEAMFORMER_SINGLE_CHANNEL) return DCS_ERR_UNSUPPORTED;
@@ -656,6 +668,7 @@ int dcs_bf_generate_and_beamform(dcs_bf_context *c, uint64_t t0, uint32_t nt, co
                                  size_t antenna_bytes, float *d_beams, size_t beams_bytes, void *stream)
 {
     if (!c || (nt && (!d_antenna || !d_beams))) return DCS_ERR_INVALID_ARGUMENT;
+    DCS_CHECK_DEVICE(c);
     if ((t0 % 16u) || (nt % 16u)) return DCS_ERR_INVALID_ARGUMENT; // INTERNAL_TIME_SAMPLES, BeamformerParameters.h:51
     if (!c->table_set) return DCS_ERR_NOT_READY;
     const uint32_t A = (uint32_t)c->p.nr_stations, B = (uint32_t)c->p.nr_beams, C = (uint32_t)c->p.nr_channels;
@@ -718,6 +731,7 @@ int dcs_bf_autotune(dcs_bf_context *c, int bitwidth, void *d_out, size_t out_byt
                     dcs_bf_tuning *chosen)
 {
     if (!c || !d_out) return DCS_ERR_INVALID_ARGUMENT;
+    DCS_CHECK_DEVICE(c);
     if (bitwidth != DCS_BF_B16 && bitwidth != DCS_BF_B32) return DCS_ERR_INVALID_ARGUMENT;
     if (!c->table_set) return DCS_ERR_NOT_READY;
     const bool out16 = bitwidth == DCS_BF_B16;
@@ -856,6 +870,7 @@ int dcs_bf_stream_begin(dcs_bf_context *c, int bitwidth, uint32_t c0, uint32_t n
                         void *stream, dcs_bf_stream **out)
 {
     if (!c || !out || !d_out) return DCS_ERR_INVALID_ARGUMENT;
+    DCS_CHECK_DEVICE(c);
     *out = nullptr;
     if (bitwidth != DCS_BF_B16 && bitwidth != DCS_BF_B32) return DCS_ERR_INVALID_ARGUMENT;
     if (!c->table_set) return DCS_ERR_NOT_READY;
@@ -900,6 +915,7 @@ int dcs_bf_stream_tick(dcs_bf_stream *s, uint64_t t, const dcs_delay_vals *new_t
 {
     if (!s) return DCS_ERR_INVALID_ARGUMENT;
     dcs_bf_context *c = s->ctx;
+    DCS_CHECK_DEVICE(c);
     float dt;
     int st = dcs_bf_delta_times(&c->p, t, 1, &dt);
     if (st != DCS_OK) return st;

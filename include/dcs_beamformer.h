@@ -36,6 +36,7 @@ extern "C" {
 #define DCS_ERR_NOT_READY (-3)     /* e.g. generate before a delay table is set */
 #define DCS_ERR_OUT_OF_RANGE (-4)
 #define DCS_ERR_NO_DEVICE (-5)
+#define DCS_ERR_WRONG_DEVICE (-6) /* the context lives on another device than the calling thread's current one */
 
 /* "<HIP Error|dcs error>: <text>", cf. common/Utils.cpp:8-16 (gpu_assert prints
  * and exit()s; here the caller decides). Returns a static string. */

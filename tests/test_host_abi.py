@@ -109,6 +109,7 @@ def test_invalid_arguments_are_status_codes(dcs_lib):
     assert dcs_lib.dcs_bf_output_bytes(None, 1, 1, byref(n)) == _lib.DCS_ERR_INVALID_ARGUMENT
     assert b"invalid argument" in dcs_lib.dcs_error_string(_lib.DCS_ERR_INVALID_ARGUMENT)
     assert b"16 bit" in dcs_lib.dcs_error_string(_lib.DCS_ERR_UNSUPPORTED) or b"mode" in dcs_lib.dcs_error_string(_lib.DCS_ERR_UNSUPPORTED)
+    assert b"another device" in dcs_lib.dcs_error_string(_lib.DCS_ERR_WRONG_DEVICE)
     cnt = ctypes.c_int(-1)
     assert dcs_lib.dcs_device_count(byref(cnt)) == 0 and cnt.value >= 0
     if cnt.value == 0:  # no GPU here: creating a context is refused, not emulated
