@@ -67,7 +67,20 @@ def main():
     np.savez_compressed(HERE / "config2_64x64x4096_seeded.npz", **arrays)
     cases.append(dict(file="config2_64x64x4096_seeded.npz", C=C, A=A, B=B, input="seeded", seed=0x5EED, slabs=slabs, checksums=cks))
 
-    (HERE / "manifest.json").write_text(json.dumps(dict(parity="unpinned", generator="tests/golden/make_golden.py", cases=cases), indent=1))
+    # The one fixture that comes from the REFERENCE ITSELF: its data-contract header compiled where it lies
+    # (oracle/ref_contract.cpp, `make -C oracle ref`); regenerated only where the reference tree is present.
+    contract = None
+    ref_bin = HERE.parent.parent / "oracle" / "_ref" / "ref_contract"
+    if Path("/root/reference/beamformer_coefficient_generator/BeamformerParameters.h").exists():
+        import subprocess
+
+        subprocess.run(["make", "-C", str(HERE.parent.parent / "oracle"), "ref"], check=True, capture_output=True)
+        (HERE / "reference_contract.json").write_text(subprocess.run([str(ref_bin)], check=True, capture_output=True, text=True).stdout)
+    if (HERE / "reference_contract.json").exists():
+        contract = dict(file="reference_contract.json", pinned_by="the reference's own header, compiled (oracle/ref_contract.cpp)",
+                        covers="struct delay_vals layout and the compile-time constants (SURVEY 8 row a0) -- not the arithmetic")
+    (HERE / "manifest.json").write_text(json.dumps(dict(parity="unpinned", generator="tests/golden/make_golden.py", cases=cases,
+                                                        reference_contract=contract), indent=1))
     for f in sorted(HERE.glob("*.npz")):
         print(f.name, f.stat().st_size)
 
