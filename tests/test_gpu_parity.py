@@ -386,6 +386,9 @@ def test_config3_full_size_sampled_channels_and_properties(gpu, oracle):
         mx, n_over, first = oracle.max_ulp(host, exp, 1)
         assert n_over == 0, (c, mx, first)
         worst = max(worst, mx)
+        with oracle.trig_reading(oracle.FLOAT_LIBM):  # the verifier's other reading; |fRotation| < 100 here
+            n_over_f = oracle.max_ulp(host, oracle.generate(op, table, t, 1, c, 1), 1)[1]
+        assert n_over_f == 0, c
         mod = np.hypot(host[..., 0].astype(np.float64), host[..., 1].astype(np.float64))
         assert np.max(np.abs(mod - 1.0)) < 2e-7
     assert worst <= 1
