@@ -43,8 +43,8 @@ def _common(d, n_gpus=1):
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
     assert r["traffic"] is None  # PMC traffic is committed for the headline workload only; nothing is invented
-    # value = coefficients of all steps / wall time; the kernel-only rate cannot be lower
-    assert 0 < d["value"] * 8 <= r["achieved"] * 1.001
+    # value = coefficients of all ranks' steps / wall time; rank 0's kernel-only rate cannot be lower than its share
+    assert 0 < d["value"] * 8 / n_gpus <= r["achieved"] * 1.001
 
 
 def test_single_gpu_line_with_cpu_baseline():
@@ -61,3 +61,23 @@ def test_collective_control_flow_over_rccl_world_of_one():
     _common(d)
     assert d["config"]["collective"] == "RCCL broadcast"
     assert "cpu_baseline" not in d
+
+
+def test_two_ranks_sharing_the_gpu_over_gloo():
+    """The N = 2 control flow with a real inter-process broadcast (gloo; both ranks on GPU 0 -- a rehearsal, never
+    a result): launched exactly as the driver launches N > 1, every rank checks its own beam slab against the
+    oracle, rank 0 alone prints the line."""
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29578", str(ROOT / "bench.py"), "--gpus", "2", *SMALL, "--backend", "gloo", "--shared-device",
+           "--check-all-ranks", "--no-cpu-baseline"]
+    res = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900, cwd=str(ROOT))
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [l for l in res.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, res.stdout[:500]
+    d = json.loads(lines[0])
+    _common(d, n_gpus=2)
+    assert "gloo" in d["config"]["collective"] and "REHEARSAL" in d["config"]["collective"]
+    assert d["config"]["coeffs_per_step"] == 2 * 16 * 64 * 2048
