@@ -7,8 +7,11 @@
  * returns an int status (0 = DCS_OK, > 0 = a hipError_t value, < 0 = one of the
  * DCS_ERR_* codes below) and never exits, throws or prints.  All device work is
  * enqueued on the caller's hipStream_t (passed as void*, NULL = the null
- * stream) so the calls can be captured in a hipGraph; nothing here starts host
- * threads.
+ * stream) so the calls can be captured in a hipGraph (dcs_bf_generate /
+ * dcs_bf_generate_slab in the default tiled form for up to 256 time steps per
+ * call: longer calls, the rows form and the fused kernel stage tables through
+ * pinned memory or allocate on first use and are not capturable); nothing here
+ * starts host threads.
  *
  * Each declaration cites the reference interface it replaces (paths relative
  * to the reference root; "BCT" = beamformer_coefficient_generator/

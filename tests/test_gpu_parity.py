@@ -850,3 +850,51 @@ def test_seeded_fuzz_of_shapes_slabs_time_ranges_and_geometries(gpu, oracle):
             buf32.free()
         g.close()
         buf.free()
+
+
+@pytest.mark.parametrize("nt", [1, 256])
+def test_generate_under_stream_capture(gpu, oracle, nt):
+    """include/dcs_beamformer.h: "all device work is enqueued on the caller's stream so the calls can be
+    captured in a hipGraph".  dcs_bf_generate under hipStreamBeginCapture / EndCapture (up to 256 time steps:
+    their fDeltaTime values are kernel arguments; longer launches stage a table through pinned memory and
+    are not capturable), instantiated and replayed twice: the replays write what a direct launch writes."""
+    import ctypes
+
+    from dc_sand_amd import BeamformerParameters
+    from dc_sand_amd.generator import SteeringCoefficientGenerator
+
+    hip = ctypes.CDLL("libamdhip64.so")
+    V = ctypes.c_void_p
+    hip.hipStreamBeginCapture.argtypes = [V, ctypes.c_int]
+    hip.hipStreamEndCapture.argtypes = [V, ctypes.POINTER(V)]
+    hip.hipGraphInstantiate.argtypes = [ctypes.POINTER(V), V, V, V, ctypes.c_size_t]
+    hip.hipGraphLaunch.argtypes = [V, V]
+    hip.hipGraphExecDestroy.argtypes = [V]
+    hip.hipGraphDestroy.argtypes = [V]
+
+    bp = BeamformerParameters(NR_CHANNELS=24, NR_STATIONS=5, NR_BEAMS=13)
+    table = rand_table(bp.n_pairs, seed=31)
+    g = SteeringCoefficientGenerator(bp)
+    g.upload_delays(table)
+    gpu.synchronize()
+    nbytes = g.output_bytes(1, nt)
+    buf = gpu.mem_alloc(nbytes)
+    s = gpu.Stream()
+    assert hip.hipStreamBeginCapture(V(s.handle), 0) == 0  # hipStreamCaptureModeGlobal
+    g.generate(buf, nbytes, t0=7, nt=nt, stream=s.handle)
+    graph = V()
+    assert hip.hipStreamEndCapture(V(s.handle), ctypes.byref(graph)) == 0 and graph.value
+    ex = V()
+    assert hip.hipGraphInstantiate(ctypes.byref(ex), graph, None, None, 0) == 0
+    exp = oracle.generate(oracle.params_from(bp), table, 7, nt)
+    for _ in range(2):
+        gpu.memset(buf, 0xFF, nbytes, stream=s.handle)  # nothing was generated yet by the capture itself
+        assert hip.hipGraphLaunch(ex, V(s.handle)) == 0
+        s.synchronize()
+        got = np.empty(exp.shape, dtype=np.float32)
+        gpu.memcpy_dtoh(got, buf)
+        _check(oracle, got, exp)
+    hip.hipGraphExecDestroy(ex)
+    hip.hipGraphDestroy(graph)
+    g.close()
+    buf.free()
