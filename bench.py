@@ -170,6 +170,11 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     N = max(world, 1)
 
+    # the host driver of this pool only supports dmabuf IPC; without this RCCL's cross-process buffer
+    # registration fails (hipIpcGetMemHandle: invalid argument).  Already exported on the boxes; kept here
+    # so that the N > 1 path does not depend on the caller's environment.  Must precede HIP initialisation.
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
     import torch
 
     if not torch.cuda.is_available():
