@@ -806,8 +806,32 @@ int dcs_bf_autotune(dcs_bf_context *c, int bitwidth, void *d_out, size_t out_byt
     for (int i = 0; i < ncand; i++) // selection sort, ncand <= 32
         for (int j = i + 1; j < ncand; j++)
             if (cands[order[j]].best_ms < cands[order[i]].best_ms) { const int t = order[i]; order[i] = order[j]; order[j] = t; }
-    const int nfinal = ncand < 4 ? ncand : 4;
-    double final_ms[4] = {0.0, 0.0, 0.0, 0.0};
+    int nfinal = ncand < 4 ? ncand : 4;
+    // the library default always takes part, so that the tuner cannot end below it by mis-ranking a short trial
+    {
+        int tpb_d;
+        uint32_t cpb_d;
+        bool nt_d;
+        dcs_bf_tuning none;
+        std::memset(&none, 0, sizeof(none));
+        const dcs_bf_tuning keep = c->tune;
+        c->tune = none;
+        c->tune.nontemporal = -1;
+        pick_geometry(c, out16, nc, 1, &tpb_d, &cpb_d, &nt_d);
+        const int wpc_d = pick_wg_per_cu(c, out16);
+        c->tune = keep;
+        int pos = -1;
+        for (int i = 0; i < ncand; i++)
+            if (cands[order[i]].tpb == tpb_d && cands[order[i]].cpb == (int)cpb_d &&
+                (cands[order[i]].wpc > 0 ? cands[order[i]].wpc : 0) == wpc_d)
+                pos = i;
+        if (pos >= nfinal && nfinal < 5) { // move it to the end of the finalists
+            const int t = order[pos];
+            for (int i = pos; i > nfinal; i--) order[i] = order[i - 1];
+            order[nfinal++] = t;
+        }
+    }
+    double final_ms[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
     const int n_final = (int)std::fmin(800.0, std::fmax(8.0, std::ceil(12.0 / one)));
     for (int rnd = 0; rnd < 2 && st == 0; rnd++) {
         for (int f = 0; f < nfinal && st == 0; f++) {
