@@ -717,7 +717,7 @@ int dcs_bf_generate_and_beamform(dcs_bf_context *c, uint64_t t0, uint32_t nt, co
         a.nt16_total = nt / 16u;
         // enough workgroups to fill the chip, but keep a few channels per workgroup
         // so the staged terms lines are reused from L1
-        uint32_t cpb = 8;
+        uint32_t cpb = 4; // 4 / 8 / 16 / 32 measured: 4 is best by 1 % at 64 antennas and by 5 % at 256 (profiles/r01_fused.md)
         while (cpb > 1 && (uint64_t)((B + 15u) / 16u) * ((C + cpb - 1) / cpb) * a.nt16 < 2048u) cpb >>= 1;
         a.chan_per_block = cpb;
         a.k = c->k;

@@ -523,7 +523,7 @@ def test_fused_harness_and_slow_path(gpu, oracle):
 @pytest.mark.parametrize("A,B,C", [(9, 16, 16384), (130, 16, 4096)])
 def test_fused_slow_path_with_several_channels_per_pass(gpu, oracle, A, B, C):
     """The fused kernel's slow branch when a pass covers 4 channels (<= 64 antennas) or 2 (more: the
-    antennas also cross the 128-antenna LDS chunk): enough channels that the launcher keeps 8 per
+    antennas also cross the 128-antenna LDS chunk): enough channels that the launcher keeps 4 per
     workgroup, and slow-class pairs so that every 16-sample block takes the branch."""
     from dc_sand_amd import BeamformerParameters
     from dc_sand_amd.generator import SteeringCoefficientGenerator
