@@ -17,11 +17,19 @@ ROOT = Path(__file__).resolve().parent.parent
 SMALL = ["--ant", "16", "--beams-per-gpu", "64", "--chan", "2048", "--steps", "5", "--warmup", "2", "--no-extras"]
 
 
+def _free_port() -> str:
+    import socket
+
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return str(sk.getsockname()[1])
+
+
 def _run(extra):
     env = dict(os.environ)
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):  # a plain single-process run
         env.pop(k, None)
-    env["MASTER_PORT"] = "29577"
+    env["MASTER_PORT"] = _free_port()
     res = subprocess.run([sys.executable, str(ROOT / "bench.py"), *SMALL, *extra], capture_output=True, text=True, env=env,
                          timeout=600, cwd=str(ROOT))
     assert res.returncode == 0, res.stderr[-2000:]
@@ -71,7 +79,7 @@ def test_two_ranks_sharing_the_gpu_over_gloo():
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(k, None)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29578", str(ROOT / "bench.py"), "--gpus", "2", *SMALL, "--backend", "gloo", "--shared-device",
+           "--master-port", _free_port(), str(ROOT / "bench.py"), "--gpus", "2", *SMALL, "--backend", "gloo", "--shared-device",
            "--check-all-ranks", "--no-cpu-baseline"]
     res = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900, cwd=str(ROOT))
     assert res.returncode == 0, res.stderr[-2000:]
