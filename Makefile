@@ -11,16 +11,21 @@ LIB     := dc_sand_amd/csrc/libdcs_beamformer.so
 SRCS    := dc_sand_amd/csrc/bf_kernels.hip dc_sand_amd/csrc/bf_capi.hip
 HDRS    := dc_sand_amd/csrc/bf_kernels.h dc_sand_amd/csrc/bf_math.h include/dcs_beamformer.h
 # -ffp-contract=off is part of the numerical contract; keep in step with dc_sand_amd/build.py
-HIPFLAGS := --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-fast-math -fno-slp-vectorize -fPIC \
+HIPFLAGS := --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-fast-math -fno-slp-vectorize -fPIC -fvisibility=hidden \
             -Wall -Wextra -Wno-unused-parameter
 
-all: $(LIB) oracle hosts
+all: $(LIB) probes oracle hosts
 
 $(LIB): $(SRCS) $(HDRS)
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(SRCS)
 
 oracle:
 	$(MAKE) -C oracle
+
+# measurement apparatus (include/dcs_probes.h): the probe kernels + a -DDCS_PROBES build of the product sources
+probes: probes/libdcs_probes.so
+probes/libdcs_probes.so: probes/bf_probes.hip $(SRCS) $(HDRS) include/dcs_probes.h
+	$(HIPCC) $(HIPFLAGS) -DDCS_PROBES -shared -o $@ probes/bf_probes.hip $(SRCS)
 
 hosts: $(LIB) oracle
 	$(MAKE) -C tests/numerics
@@ -36,9 +41,9 @@ bench: $(LIB)
 	$(PYTHON) bench.py
 
 clean:
-	rm -f $(LIB)
+	rm -f $(LIB) probes/libdcs_probes.so
 	$(MAKE) -C oracle clean
 	$(MAKE) -C tests/cpp clean
 	rm -f tests/numerics/libnumerics_lab.so
 
-.PHONY: all oracle hosts test-cpu test-gpu bench clean
+.PHONY: all oracle probes hosts test-cpu test-gpu bench clean

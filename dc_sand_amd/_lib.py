@@ -86,11 +86,6 @@ SIGNATURES = [
     ("dcs_bf_stream_begin", c_int, [_VP, c_int, c_uint32, c_uint32, _VP, c_size_t, _VP, POINTER(_VP)]),
     ("dcs_bf_stream_tick", c_int, [_VP, c_uint64, _VP]),
     ("dcs_bf_stream_end", c_int, [_VP]),
-    ("dcs_probe_sincos", c_int, [c_int, _VP, c_size_t, _VP, _VP, _VP]),
-    ("dcs_probe_fill", c_int, [_VP, c_size_t, c_int, _VP]),
-    ("dcs_probe_one_store", c_int, [_VP, c_size_t, c_int, c_int, c_uint32, _VP]),
-    ("dcs_probe_reduce", c_int, [_VP, c_size_t, POINTER(c_uint64), POINTER(c_float), _VP]),
-    ("dcs_probe_store_pattern", c_int, [_VP, c_uint32, c_uint32, c_uint32, c_uint32, c_int, c_int, c_int, c_uint32, _VP]),
 ]
 
 _LIB = None

@@ -40,6 +40,7 @@ def flags() -> list[str]:
         "-fno-fast-math",
         "-fno-slp-vectorize",  # v_pk_*_f32 packing costs 1.3 % (fp32) / 6 % (fp16) here: profiles/r01_geometry_sweep.md
         "-fPIC",
+        "-fvisibility=hidden",  # exported: exactly what include/dcs_beamformer.h declares
         "-Wall",
         "-Wextra",
         "-Wno-unused-parameter",

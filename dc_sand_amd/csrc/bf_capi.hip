@@ -411,7 +411,12 @@ int dcs_bf_set_tuning(dcs_bf_context *c, const dcs_bf_tuning *t)
     if (t->rows_same_tile < -1 || t->rows_same_tile > 1) return DCS_ERR_INVALID_ARGUMENT;
     if (t->xcd_remap < -1 || t->xcd_remap > 1) return DCS_ERR_INVALID_ARGUMENT;
     if (t->math_mode < 0 || t->math_mode > 3) return DCS_ERR_INVALID_ARGUMENT;
-    if (t->pace < 0 || t->pace > 4096) return DCS_ERR_INVALID_ARGUMENT;
+#ifdef DCS_PROBES
+    if (t->probe_pace < 0 || t->probe_pace > 4096) return DCS_ERR_INVALID_ARGUMENT;
+#else
+    // measurement knobs of the probes build (include/dcs_probes.h); the product library has neither
+    if (t->probe_nomath != 0 || t->probe_pace != 0) return DCS_ERR_UNSUPPORTED;
+#endif
     if (t->wg_per_cu < -1 || t->wg_per_cu == 1 || t->wg_per_cu > 7) return DCS_ERR_INVALID_ARGUMENT;
     c->tune = *t;
     // math_mode bit 0: keep the 5-op divide; bit 1: keep the full polynomials
@@ -476,8 +481,10 @@ int prepare_tiled(dcs_bf_context *c, bool out16, const float *dt_dev, float dt0,
     pick_geometry(c, out16, nc, nt, &tpb, &cpb, &ntstore);
     a.chan_per_block = cpb;
     a.xcd_remap = c->tune.xcd_remap > 0 ? 1u : 0u;
-    a.pace = (uint32_t)c->tune.pace;
-    const int st = (int)bf_prepare_tiled(a, out16, tpb | (c->tune.nomath ? 0x100 : 0) | (c->tuning_now ? 0x200 : 0), ntstore, l);
+#ifdef DCS_PROBES
+    a.pace = (uint32_t)c->tune.probe_pace;
+#endif
+    const int st = (int)bf_prepare_tiled(a, out16, tpb | (c->tune.probe_nomath ? 0x100 : 0) | (c->tuning_now ? 0x200 : 0), ntstore, l);
     const int wpc = pick_wg_per_cu(c, out16);
     if (st == DCS_OK && wpc > 0) l->shared = lds_pad_for(wpc, out16, tpb);
     return st;
@@ -543,12 +550,14 @@ int launch_rows(dcs_bf_context *c, bool out16, const float *dt_dev, float dt0, u
     const bool ntstore = c->tune.nontemporal < 0 ? true : c->tune.nontemporal != 0;
     const bool xcd = c->tune.xcd_remap < 0 ? !same_tile : c->tune.xcd_remap != 0;
     a.same_tile = same_tile ? 1u : 0u;
-    a.pace = (uint32_t)c->tune.pace;
+#ifdef DCS_PROBES
+    a.pace = (uint32_t)c->tune.probe_pace;
+#endif
     if (c->tune.wg_per_cu > 0) { // rows form: only when asked for (no default limit)
         uint32_t per = (160u * 1024u / (uint32_t)c->tune.wg_per_cu) & ~1023u;
         a.lds_pad = per > 64u * 1024u ? 64u * 1024u : per;
     }
-    return (int)bf_launch_rows(a, out16, nw, rpw, ntstore, xcd, c->tune.nomath != 0, stream);
+    return (int)bf_launch_rows(a, out16, nw, rpw, ntstore, xcd, c->tune.probe_nomath != 0, stream);
 }
 
 // form 1 = tiled (long-lived waves), 2 = rows (short waves); 0 = library default
@@ -979,61 +988,6 @@ int dcs_bf_stream_end(dcs_bf_stream *s)
     if (s->h_table) (void)hipHostFree(s->h_table);
     delete s;
     return DCS_OK;
-}
-
-/* ---- probes ------------------------------------------------------------- */
-int dcs_probe_sincos(int which, const float *d_x, size_t n, float *d_sin, float *d_cos, void *stream)
-{
-    if (which < 0 || which > 3 || (n && (!d_x || !d_sin || !d_cos))) return DCS_ERR_INVALID_ARGUMENT;
-    return (int)bf_launch_probe_sincos(which, d_x, n, d_sin, d_cos, as_stream(stream));
-}
-
-int dcs_probe_fill(void *d_out, size_t bytes, int nontemporal, void *stream)
-{
-    if (!d_out && bytes) return DCS_ERR_INVALID_ARGUMENT;
-    return (int)bf_launch_probe_fill(d_out, bytes, nontemporal != 0, as_stream(stream));
-}
-
-int dcs_probe_store_pattern(void *d_out, uint32_t rows, uint32_t cols_kib, uint32_t qb, uint32_t rb, int order,
-                            int xcd_remap, int nontemporal, uint32_t block_threads, void *stream)
-{
-    if (!d_out) return DCS_ERR_INVALID_ARGUMENT;
-    return (int)bf_launch_probe_pattern(d_out, rows, cols_kib, qb, rb, (uint32_t)order, (uint32_t)xcd_remap,
-                                        nontemporal, block_threads, as_stream(stream));
-}
-
-int dcs_probe_one_store(void *d_out, size_t bytes, int store_mode, int stores_per_thread, uint32_t row_bytes, void *stream)
-{
-    if (!d_out || (bytes % 4096u) || stores_per_thread < 1 || stores_per_thread > 64) return DCS_ERR_INVALID_ARGUMENT;
-    if (stores_per_thread > 1 && (row_bytes == 0 || (row_bytes % 1024u) || bytes % ((size_t)row_bytes * 4u * (size_t)stores_per_thread)))
-        return DCS_ERR_INVALID_ARGUMENT;
-    return (int)bf_launch_probe_one_store(d_out, bytes, store_mode, stores_per_thread, row_bytes, as_stream(stream));
-}
-
-int dcs_probe_reduce(const void *d_in, size_t bytes, uint64_t *checksum, float *max_modulus_dev, void *stream)
-{
-    if ((!d_in && bytes) || !checksum || !max_modulus_dev || (bytes % 16u)) return DCS_ERR_INVALID_ARGUMENT;
-    const size_t n = 2 * (size_t)BF_PROBE_REDUCE_WAVES;
-    unsigned long long *d_part = nullptr;
-    unsigned long long *h_part = new (std::nothrow) unsigned long long[n];
-    if (!h_part) return (int)hipErrorOutOfMemory;
-    hipError_t e = hipMalloc((void **)&d_part, n * sizeof(unsigned long long));
-    if (e == hipSuccess) e = bf_launch_probe_reduce(d_in, bytes, d_part, as_stream(stream));
-    if (e == hipSuccess) e = hipMemcpyAsync(h_part, d_part, n * sizeof(unsigned long long), hipMemcpyDeviceToHost, as_stream(stream));
-    if (e == hipSuccess) e = hipStreamSynchronize(as_stream(stream));
-    if (d_part) (void)hipFree(d_part);
-    if (e == hipSuccess) {
-        uint64_t sum = 0;
-        uint32_t devbits = 0;
-        for (size_t w = 0; w < n / 2; w++) {
-            sum += h_part[2 * w];
-            if ((uint32_t)h_part[2 * w + 1] > devbits) devbits = (uint32_t)h_part[2 * w + 1];
-        }
-        *checksum = sum;
-        std::memcpy(max_modulus_dev, &devbits, sizeof(float));
-    }
-    delete[] h_part;
-    return (int)e;
 }
 
 } // extern "C"

@@ -22,7 +22,9 @@ struct bf_tiled_args {
     uint32_t n_tile_groups;       // ceil(n_pairs / pairs per workgroup)
     uint32_t n_cblocks;           // ceil(nc / chan_per_block)
     uint32_t xcd_remap;           // workgroups sharing blockIdx % 8 (one XCD) take consecutive (tile, channel block)s
-    uint32_t pace;                // 64-cycle sleeps before each store of the fast loop (tuning knob)
+#ifdef DCS_PROBES
+    uint32_t pace;                // probes build only: 64-cycle sleeps before each store of the fast loop
+#endif
     dcs_bf_consts k;
     // fDeltaTime of up to kDtInline time steps by value (kernel arguments): the reference's default
     // tensor (256 time steps, 134 MB) is a 22 us kernel, and a pinned->device copy of the dt table in
@@ -69,7 +71,9 @@ struct bf_rows_args {
     uint32_t xcd_remap;
     uint32_t div3; // dcs_bf_consts::uDiv3Exact
     uint32_t same_tile; // the workgroup's waves share one tile and interleave rows
-    uint32_t pace;      // 64-cycle sleeps before each store (tuning knob)
+#ifdef DCS_PROBES
+    uint32_t pace;      // probes build only: 64-cycle sleeps before each store
+#endif
     uint32_t lds_pad;   // host only: dynamic LDS the launch asks for (occupancy limiter, unused by the kernel)
     float D, y;
 };
@@ -118,16 +122,6 @@ hipError_t bf_launch_gather_beams(dcs_delay_vals *local, const dcs_delay_vals *g
                                   uint32_t n_ant, uint32_t n_beams_local, uint32_t n_beams_total,
                                   uint32_t beam_offset, hipStream_t stream);
 
-hipError_t bf_launch_probe_sincos(int which, const float *x, size_t n, float *s, float *c,
-                                  hipStream_t stream);
-hipError_t bf_launch_probe_fill(void *out, size_t bytes, bool nontemporal, hipStream_t stream);
-hipError_t bf_launch_probe_pattern(void *out, uint32_t rows, uint32_t cols, uint32_t QB, uint32_t RB,
-                                   uint32_t order, uint32_t xcd, int store_mode, uint32_t block_threads,
-                                   hipStream_t stream);
-#define BF_PROBE_REDUCE_WAVES 8192
-hipError_t bf_launch_probe_reduce(const void *in, size_t bytes, unsigned long long *d_part, hipStream_t stream);
-hipError_t bf_launch_probe_one_store(void *out, size_t bytes, int store_mode, int stores_per_thread, uint32_t row_bytes,
-                                     hipStream_t stream);
 hipError_t bf_warm_module();
 hipError_t bf_launch_verify_div3(float D, float y, uint32_t *d_mismatches, hipStream_t stream);
 

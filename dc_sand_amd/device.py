@@ -186,11 +186,3 @@ class Event:
                 self.handle = None
         except Exception:
             pass
-
-
-def tensor_properties(d_ptr, nbytes: int, stream=None) -> tuple[int, float]:
-    """(checksum, max | |z|^2 - 1 |) of an fp32 coefficient tensor on the device."""
-    ck = ctypes.c_uint64(0)
-    dev = c_float(0.0)
-    check(_lib.lib().dcs_probe_reduce(c_void_p(int(d_ptr)), int(nbytes), byref(ck), byref(dev), _s(stream)), "dcs_probe_reduce")
-    return int(ck.value), float(dev.value)

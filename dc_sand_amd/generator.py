@@ -111,15 +111,16 @@ class SteeringCoefficientGenerator:
         )
 
     def set_tuning(self, form: int = 0, nontemporal: int = -1, chan_per_block: int = 0, tiles_per_block: int = 0,
-                   waves_per_block: int = 0, rows_per_wave: int = 0, xcd_remap: int = -1, nomath: bool = False,
-                   rows_same_tile: int = -1, pace: int = 0, math_mode: int = 0, wg_per_cu: int = 0) -> None:
-        """``struct dcs_bf_tuning``; ``set_tuning()`` restores the defaults."""
+                   waves_per_block: int = 0, rows_per_wave: int = 0, xcd_remap: int = -1, probe_nomath: bool = False,
+                   rows_same_tile: int = -1, probe_pace: int = 0, math_mode: int = 0, wg_per_cu: int = 0) -> None:
+        """``struct dcs_bf_tuning``; ``set_tuning()`` restores the defaults.  ``probe_nomath`` / ``probe_pace`` are
+        honoured only by the probes build of the library (include/dcs_probes.h); the product library refuses them."""
         t = (ctypes.c_int32 * 12)(form, nontemporal, chan_per_block, tiles_per_block, waves_per_block, rows_per_wave,
-                                  xcd_remap, 1 if nomath else 0, rows_same_tile, pace, math_mode, wg_per_cu)
+                                  xcd_remap, 1 if probe_nomath else 0, rows_same_tile, probe_pace, math_mode, wg_per_cu)
         check(_lib.lib().dcs_bf_set_tuning(c_void_p(self._h), ctypes.cast(t, c_void_p)), "dcs_bf_set_tuning")
 
     TUNING_FIELDS = ("form", "nontemporal", "chan_per_block", "tiles_per_block", "waves_per_block", "rows_per_wave",
-                     "xcd_remap", "nomath", "rows_same_tile", "pace", "math_mode", "wg_per_cu")
+                     "xcd_remap", "probe_nomath", "rows_same_tile", "probe_pace", "math_mode", "wg_per_cu")
 
     def autotune(self, d_out, out_bytes: int, bitwidth: int = B32, stream=None) -> dict:
         """``dcs_bf_autotune``: time the tiled form's geometries on this device for this

@@ -29,6 +29,8 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* the libraries are built -fvisibility=hidden: only what this header declares is exported */
+#pragma GCC visibility push(default)
 
 #define DCS_BF_ABI_VERSION 1
 
@@ -198,10 +200,10 @@ struct dcs_bf_tuning {
     int32_t waves_per_block; /* form 2: 4, 8, 16 */
     int32_t rows_per_wave;   /* form 2: 1..4 */
     int32_t xcd_remap;       /* -1 default, 0, 1: workgroups sharing blockIdx % 8 (one XCD) take consecutive work */
-    int32_t nomath;          /* probe: addressing and stores only */
+    int32_t probe_nomath;    /* must be 0 (libdcs_probes.so only: addressing and stores, no arithmetic) */
     int32_t rows_same_tile;  /* form 2: -1 default, 0 = the waves take adjacent tiles, 1 = they share one tile and
                               * interleave rows */
-    int32_t pace;            /* sleep this many 64-cycle units before each store (0 = none) */
+    int32_t probe_pace;      /* must be 0 (libdcs_probes.so only: 64-cycle sleeps before each store) */
     int32_t math_mode;       /* A/B of the arithmetic forms (all give the same bits): bit 0 = keep the 5-op
                               * divide even where the 3-op form was verified exact for this divisor; bit 1 =
                               * keep the full-degree polynomials even where the low-degree ones are proven */
@@ -241,35 +243,7 @@ int dcs_bf_stream_begin(dcs_bf_context *ctx, int bitwidth, uint32_t c0, uint32_t
 int dcs_bf_stream_tick(dcs_bf_stream *s, uint64_t t, const struct dcs_delay_vals *new_table);
 int dcs_bf_stream_end(dcs_bf_stream *s);
 
-/* ---- probes (used by tests / bench to characterise the device) ----------- */
-/* Device evaluation of the two sincos forms on n arguments:
- * which = 0 the library's fast path (full polynomials), 1 __ocml_sincos_f32, 2 the fp64
- * slow path, 3 the fast path with the low-degree polynomials (valid below 512). */
-int dcs_probe_sincos(int which, const float *d_x, size_t n, float *d_sin, float *d_cos, void *stream);
-/* Pure store kernel with the generator's access pattern and no arithmetic: the
- * measured HBM-write ceiling the roofline fraction is read against. */
-int dcs_probe_fill(void *d_out, size_t bytes, int nontemporal, void *stream);
-/* Store-only kernel over a `rows` x `cols_kib` KiB matrix: each workgroup owns a
- * rectangle of rb rows x qb KiB (tools/explore_patterns.py maps out which write
- * patterns the HBM system sustains; profiles/r01_store_patterns.md).  xcd_remap is a
- * bit set: 1 = workgroups sharing blockIdx % 8 take consecutive rectangles, 2 = a wave
- * takes consecutive 1-KiB chunks instead of every n-th, bits 4-6 = rotate the rectangle
- * column within groups of 8 (XCD <-> address affinity probe).  `nontemporal` selects the
- * store's cache policy: 0 plain, 1 nt, 2 sc1 (write-through), 3 sc0 sc1, 4 sc1 nt. */
-int dcs_probe_store_pattern(void *d_out, uint32_t rows, uint32_t cols_kib, uint32_t qb, uint32_t rb, int order,
-                            int xcd_remap, int nontemporal, uint32_t block_threads, void *stream);
-
-/* The leanest store kernels (no loop, no integer division): stores_per_thread = 1 writes
- * the buffer linearly, one 16-byte store per thread; 2..4 writes it as rows of row_bytes with
- * the generator's pattern (a 4-wave workgroup = one 1-KiB tile x 4*stores_per_thread rows).
- * store_mode 0 plain, 1 nontemporal. */
-int dcs_probe_one_store(void *d_out, size_t bytes, int store_mode, int stores_per_thread, uint32_t row_bytes, void *stream);
-
-/* Whole-tensor properties of an fp32 coefficient tensor resident on the device:
- * checksum = sum of its 32-bit words mod 2^64 (order independent), and
- * max | re^2 + im^2 - 1 | (inf if any NaN).  Synchronises `stream`. */
-int dcs_probe_reduce(const void *d_in, size_t bytes, uint64_t *checksum, float *max_modulus_dev, void *stream);
-
+#pragma GCC visibility pop
 #ifdef __cplusplus
 }
 #endif

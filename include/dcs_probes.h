@@ -1,0 +1,56 @@
+/*
+ * dcs_probes.h -- measurement apparatus of the MI355X steering-coefficient generator.
+ * NOT part of the product ABI (include/dcs_beamformer.h): nothing a caller of the hot path
+ * needs is here.  Library: probes/libdcs_probes.so (`python -m probes.build`), which holds
+ *   - the dcs_probe_* entry points below (probes/bf_probes.hip), and
+ *   - a second build of the product sources with -DDCS_PROBES, i.e. the whole dcs_bf_* API
+ *     with dcs_bf_tuning::probe_nomath (store-only skeleton of the generator) and
+ *     dcs_bf_tuning::probe_pace (sleep before each store) honoured -- libdcs_beamformer.so
+ *     answers DCS_ERR_UNSUPPORTED to either.
+ * Users: tests/ (device sincos sweep, whole-tensor checksum of the full-size configs) and
+ * tools/measure.py (the store-pattern studies behind profiles/r01_store_patterns.md).
+ */
+#ifndef DCS_PROBES_H
+#define DCS_PROBES_H
+
+#include "dcs_beamformer.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+/* the libraries are built -fvisibility=hidden: only what this header declares is exported */
+#pragma GCC visibility push(default)
+
+/* Device evaluation of the two sincos forms on n arguments:
+ * which = 0 the library's fast path (full polynomials), 1 __ocml_sincos_f32, 2 the fp64
+ * slow path, 3 the fast path with the low-degree polynomials (valid below 512). */
+int dcs_probe_sincos(int which, const float *d_x, size_t n, float *d_sin, float *d_cos, void *stream);
+/* Pure store kernel with the generator's access pattern and no arithmetic: the
+ * measured HBM-write ceiling the roofline fraction is read against. */
+int dcs_probe_fill(void *d_out, size_t bytes, int nontemporal, void *stream);
+/* Store-only kernel over a `rows` x `cols_kib` KiB matrix: each workgroup owns a
+ * rectangle of rb rows x qb KiB (tools/explore_patterns.py maps out which write
+ * patterns the HBM system sustains; profiles/r01_store_patterns.md).  xcd_remap is a
+ * bit set: 1 = workgroups sharing blockIdx % 8 take consecutive rectangles, 2 = a wave
+ * takes consecutive 1-KiB chunks instead of every n-th, bits 4-6 = rotate the rectangle
+ * column within groups of 8 (XCD <-> address affinity probe).  `nontemporal` selects the
+ * store's cache policy: 0 plain, 1 nt, 2 sc1 (write-through), 3 sc0 sc1, 4 sc1 nt. */
+int dcs_probe_store_pattern(void *d_out, uint32_t rows, uint32_t cols_kib, uint32_t qb, uint32_t rb, int order,
+                            int xcd_remap, int nontemporal, uint32_t block_threads, void *stream);
+
+/* The leanest store kernels (no loop, no integer division): stores_per_thread = 1 writes
+ * the buffer linearly, one 16-byte store per thread; 2..4 writes it as rows of row_bytes with
+ * the generator's pattern (a 4-wave workgroup = one 1-KiB tile x 4*stores_per_thread rows).
+ * store_mode 0 plain, 1 nontemporal. */
+int dcs_probe_one_store(void *d_out, size_t bytes, int store_mode, int stores_per_thread, uint32_t row_bytes, void *stream);
+
+/* Whole-tensor properties of an fp32 coefficient tensor resident on the device:
+ * checksum = sum of its 32-bit words mod 2^64 (order independent), and
+ * max | re^2 + im^2 - 1 | (inf if any NaN).  Synchronises `stream`. */
+int dcs_probe_reduce(const void *d_in, size_t bytes, uint64_t *checksum, float *max_modulus_dev, void *stream);
+
+#pragma GCC visibility pop
+#ifdef __cplusplus
+}
+#endif
+#endif /* DCS_PROBES_H */

@@ -1,0 +1,78 @@
+"""ctypes binding of ``include/dcs_probes.h`` (probes/libdcs_probes.so).  Test and measurement
+infrastructure: the product package never imports this.
+
+The probes library also exports the whole ``dcs_bf_*`` API built with ``-DDCS_PROBES``
+(``probe_nomath`` / ``probe_pace`` honoured); to drive it through the ordinary Python wrappers
+start the process with ``DCS_LIB_PATH=probes/libdcs_probes.so``.
+"""
+from __future__ import annotations
+
+import ctypes
+from ctypes import POINTER, byref, c_float, c_int, c_size_t, c_uint32, c_uint64, c_void_p
+
+import numpy as np
+
+from .build import LIB, build
+
+_VP = c_void_p
+SIGNATURES = [
+    ("dcs_probe_sincos", c_int, [c_int, _VP, c_size_t, _VP, _VP, _VP]),
+    ("dcs_probe_fill", c_int, [_VP, c_size_t, c_int, _VP]),
+    ("dcs_probe_one_store", c_int, [_VP, c_size_t, c_int, c_int, c_uint32, _VP]),
+    ("dcs_probe_reduce", c_int, [_VP, c_size_t, POINTER(c_uint64), POINTER(c_float), _VP]),
+    ("dcs_probe_store_pattern", c_int, [_VP, c_uint32, c_uint32, c_uint32, c_uint32, c_int, c_int, c_int, c_uint32, _VP]),
+]
+
+_LIB = None
+
+
+def lib() -> ctypes.CDLL:
+    global _LIB
+    if _LIB is None:
+        if not LIB.exists():
+            build()
+        L = ctypes.CDLL(str(LIB))
+        for name, restype, argtypes in SIGNATURES:
+            fn = getattr(L, name)
+            fn.restype = restype
+            fn.argtypes = argtypes
+        _LIB = L
+    return _LIB
+
+
+def _check(status: int, where: str) -> None:
+    if status != 0:
+        raise RuntimeError(f"{where}: status {status}")
+
+
+def _s(stream) -> c_void_p:
+    if stream is None:
+        return c_void_p(None)
+    return c_void_p(int(getattr(stream, "handle", stream)))
+
+
+def tensor_properties(d_ptr, nbytes: int, stream=None) -> tuple[int, float]:
+    """(checksum, max | |z|^2 - 1 |) of an fp32 coefficient tensor on the device."""
+    ck = c_uint64(0)
+    dev = c_float(0.0)
+    _check(lib().dcs_probe_reduce(c_void_p(int(d_ptr)), int(nbytes), byref(ck), byref(dev), _s(stream)), "dcs_probe_reduce")
+    return int(ck.value), float(dev.value)
+
+
+def sincos(which: int, d_x, n: int, d_sin, d_cos, stream=None) -> None:
+    _check(lib().dcs_probe_sincos(int(which), c_void_p(int(d_x)), int(n), c_void_p(int(d_sin)), c_void_p(int(d_cos)), _s(stream)),
+           "dcs_probe_sincos")
+
+
+def fill(d_out, nbytes: int, nontemporal: int = 1, stream=None) -> None:
+    _check(lib().dcs_probe_fill(c_void_p(int(d_out)), int(nbytes), int(nontemporal), _s(stream)), "dcs_probe_fill")
+
+
+def store_pattern(d_out, rows, cols_kib, qb, rb, order=0, xcd_remap=0, store_mode=1, block_threads=256, stream=None) -> None:
+    _check(lib().dcs_probe_store_pattern(c_void_p(int(d_out)), rows, cols_kib, qb, rb, order, xcd_remap, store_mode, block_threads,
+                                         _s(stream)), "dcs_probe_store_pattern")
+
+
+def one_store(d_out, nbytes, store_mode, stores_per_thread, row_bytes, stream=None) -> None:
+    _check(lib().dcs_probe_one_store(c_void_p(int(d_out)), int(nbytes), int(store_mode), int(stores_per_thread), int(row_bytes),
+                                     _s(stream)), "dcs_probe_one_store")

@@ -45,6 +45,16 @@ def gpu(dcs_lib):
     return device
 
 
+@pytest.fixture(scope="session")
+def probes(gpu):
+    """probes/libdcs_probes.so (include/dcs_probes.h): device sincos sweep and whole-tensor properties --
+    measurement apparatus kept out of the product library."""
+    from probes import build as pb, dcs_probes
+
+    pb.build()
+    return dcs_probes
+
+
 def rand_table(n: int, seed: int = 0x5EED, Ts: float = 1e-7) -> np.ndarray:
     """Input set S of SURVEY.md section 8(d): seeded uniform delay polynomials."""
     from oracle.bf_oracle import delay_vals_dtype

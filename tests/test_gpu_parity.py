@@ -119,7 +119,6 @@ TUNINGS = [
     dict(form=1, tiles_per_block=1, chan_per_block=3),
     dict(form=1, tiles_per_block=4, chan_per_block=1000),
     dict(form=1, tiles_per_block=1, chan_per_block=13, xcd_remap=1),
-    dict(form=1, tiles_per_block=1, chan_per_block=16, pace=3),
     dict(form=1, tiles_per_block=1, chan_per_block=12, wg_per_cu=-1),
     dict(form=1, tiles_per_block=2, chan_per_block=5, wg_per_cu=2),
     dict(form=1, tiles_per_block=4, chan_per_block=9, wg_per_cu=7),
@@ -247,10 +246,14 @@ def test_error_behaviour(gpu):
     with pytest.raises(_lib.DcsError) as e:
         g.generate(buf, buf.nbytes - 1)
     assert e.value.status == _lib.DCS_ERR_INVALID_ARGUMENT
-    for bad in (dict(wg_per_cu=1), dict(wg_per_cu=8), dict(wg_per_cu=-2), dict(tiles_per_block=3), dict(form=3), dict(pace=-1)):
+    for bad in (dict(wg_per_cu=1), dict(wg_per_cu=8), dict(wg_per_cu=-2), dict(tiles_per_block=3), dict(form=3), dict(math_mode=-1)):
         with pytest.raises(_lib.DcsError) as e:
             g.set_tuning(**bad)
         assert e.value.status == _lib.DCS_ERR_INVALID_ARGUMENT, bad
+    for probe_only in (dict(probe_pace=3), dict(probe_nomath=True)):  # knobs of libdcs_probes.so (include/dcs_probes.h)
+        with pytest.raises(_lib.DcsError) as e:
+            g.set_tuning(**probe_only)
+        assert e.value.status == _lib.DCS_ERR_UNSUPPORTED, probe_only
     g.close()
 
 
@@ -301,12 +304,9 @@ def test_unit_test_harness_five_phases(gpu, oracle, capsys):
         BeamformerCoeffTest(1e-4, K.NAIVE, BW.b16)
 
 
-def test_sincos_probe_fast_path_matches_host_sweep(gpu, oracle):
+def test_sincos_probe_fast_path_matches_host_sweep(gpu, oracle, probes):
     """The device evaluates dcs_sincos_fast to the same bits as the host build
     swept exhaustively in test_numerics.py (sampled: 4M arguments)."""
-    import ctypes
-    from dc_sand_amd import _lib
-
     rng = np.random.default_rng(1)
     x = np.concatenate([
         rng.uniform(-100, 100, 1 << 21).astype(np.float32),
@@ -316,9 +316,9 @@ def test_sincos_probe_fast_path_matches_host_sweep(gpu, oracle):
     n = x.size
     dx, ds, dc = gpu.mem_alloc(4 * n), gpu.mem_alloc(4 * n), gpu.mem_alloc(4 * n)
     gpu.memcpy_htod(dx, x)
-    V = ctypes.c_void_p
     for which, limit in ((0, 1), (2, 1), (3, 1)):
-        _lib.check(_lib.lib().dcs_probe_sincos(which, V(int(dx)), n, V(int(ds)), V(int(dc)), V(None)), "probe")
+        probes.sincos(which, dx, n, ds, dc)
+        gpu.synchronize()
         s = np.empty(n, np.float32)
         c = np.empty(n, np.float32)
         gpu.memcpy_dtoh(s, ds)
@@ -356,7 +356,7 @@ def test_against_committed_golden_fixtures(gpu):
             assert np.max(np.abs(gi - ei)) <= 1, (case["file"], key)
 
 
-def test_config3_full_size_sampled_channels_and_properties(gpu, oracle):
+def test_config3_full_size_sampled_channels_and_properties(gpu, oracle, probes):
     """BASELINE configs[2] at FULL size (64 x 1024 x 32768, 16 GiB on the GPU):
     a deterministic channel subset (c in {0, 1, C/2, C-1} and every 257th, all
     (antenna, beam)) is copied back and compared with the oracle in ULPs; the
@@ -397,17 +397,17 @@ def test_config3_full_size_sampled_channels_and_properties(gpu, oracle):
     # whole-tensor properties on the device: unit modulus everywhere, and the two
     # independent forms (tiled / rows: different grids and index arithmetic, both
     # 64-bit) write bit-identical 16 GiB tensors
-    ck1, dev1 = gpu.tensor_properties(buf, nbytes)
+    ck1, dev1 = probes.tensor_properties(buf, nbytes)
     assert dev1 < 4e-7
     g.set_tuning(form=2)
     gpu.memset(buf, 0, nbytes)
     g.generate(buf, nbytes, t0=t, nt=1)
-    ck2, dev2 = gpu.tensor_properties(buf, nbytes)
+    ck2, dev2 = probes.tensor_properties(buf, nbytes)
     assert ck2 == ck1 and dev2 == dev1
     # small-case anchor of the checksum itself
     small = np.empty((4, bp.NR_STATIONS, bp.NR_BEAMS, 2), dtype=np.float32)
     gpu.memcpy_dtoh(small, buf)
-    cks, _ = gpu.tensor_properties(buf, small.nbytes)
+    cks, _ = probes.tensor_properties(buf, small.nbytes)
     assert cks == oracle.checksum_of(small)
     g.close()
     buf.free()
@@ -549,7 +549,7 @@ def test_fused_slow_path_with_several_channels_per_pass(gpu, oracle, A, B, C):
     g.close()
 
 
-def test_config4_one_rank_shard_at_full_size(gpu, oracle):
+def test_config4_one_rank_shard_at_full_size(gpu, oracle, probes):
     """BASELINE configs[3]: 256 ant x 4096 beam x 32768 chan beam-sharded over 8 GPUs.
     One rank's share at FULL size on this GPU (rank 3: beams [1536, 2048), 2^32
     coefficients, 32 GiB): the slice is gathered on the device from the 16 MiB global
@@ -583,7 +583,7 @@ def test_config4_one_rank_shard_at_full_size(gpu, oracle):
         exp = oracle.generate(op, local, t, 1, c, 1)
         mx, n_over, first = oracle.max_ulp(host, exp, 1)
         assert n_over == 0, (c, mx, first)
-    ck, dev = gpu.tensor_properties(buf, nbytes)
+    ck, dev = probes.tensor_properties(buf, nbytes)
     assert dev < 4e-7
     g.close()
     buf.free()

@@ -32,6 +32,28 @@ def test_header_symbols_are_exported_and_bound(dcs_lib):
     assert dcs_lib.dcs_abi_version() == 1
 
 
+def test_product_library_exports_no_measurement_apparatus(dcs_lib):
+    """The probes (store patterns, sincos sweep, tensor checksum) live in probes/libdcs_probes.so
+    (include/dcs_probes.h), which also carries the -DDCS_PROBES build of the product sources; the product
+    library exports none of them."""
+    import subprocess
+
+    from dc_sand_amd import _lib
+    from probes import build as pb
+
+    syms = subprocess.run(["nm", "-D", "--defined-only", str(_lib.LIB_PATH)], check=True, capture_output=True, text=True).stdout
+    assert "probe" not in syms
+    exported = {l.split()[-1] for l in syms.splitlines() if " T " in l}
+    assert exported == set(_declared_functions()), exported ^ set(_declared_functions())
+    plib = pb.build()
+    psyms = subprocess.run(["nm", "-D", "--defined-only", str(plib)], check=True, capture_output=True, text=True).stdout
+    pexp = {l.split()[-1] for l in psyms.splitlines() if " T " in l}
+    text = re.sub(r"/\*.*?\*/", "", (ROOT / "include" / "dcs_probes.h").read_text(), flags=re.S)
+    declared_probes = set(re.findall(r"\b(dcs_probe_[a-z0-9_]+)\s*\(", text))
+    assert len(declared_probes) == 5 and declared_probes <= pexp
+    assert set(_declared_functions()) <= pexp  # the probes library is a superset build
+
+
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     from dc_sand_amd import _lib
 
@@ -133,16 +155,28 @@ def test_no_kernel_uses_scratch(dcs_lib, tmp_path):
         tools = [Path(p) for p in (shutil.which("llvm-objcopy"), shutil.which("clang-offload-bundler"), shutil.which("llvm-readelf")) if p]
     if len(tools) != 3:
         pytest.skip("LLVM binutils of the ROCm toolchain not found")
-    fat, co = tmp_path / "fatbin.bin", tmp_path / "gfx950.co"
-    subprocess.run([str(tools[0]), f"--dump-section=.hip_fatbin={fat}", str(_lib.LIB_PATH)], check=True, capture_output=True)
-    subprocess.run([str(tools[1]), "--unbundle", "--type=o", f"--input={fat}", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950",
-                    f"--output={co}"], check=True, capture_output=True)
-    notes = subprocess.run([str(tools[2]), "--notes", str(co)], check=True, capture_output=True, text=True).stdout
-    names = [l.split(":", 1)[1].strip() for l in notes.splitlines() if l.strip().startswith(".name:")]
-    sizes = [int(l.split(":", 1)[1]) for l in notes.splitlines() if ".private_segment_fixed_size:" in l]
-    assert len(sizes) > 100, "metadata not found"
-    bad = [(n, s) for n, s in zip([n for n in names if not n.startswith(("a", "_.")) or True][: len(sizes)], sizes) if s != 0]
-    assert not any(s for s in sizes), f"{sum(1 for s in sizes if s)} kernel(s) use scratch: {bad[:3]}"
+    from probes import build as pb
+
+    for tag, so, least in (("product", _lib.LIB_PATH, 100), ("probes", pb.build(), 120)):
+        fat = tmp_path / f"{tag}.fatbin"
+        subprocess.run([str(tools[0]), f"--dump-section=.hip_fatbin={fat}", str(so)], check=True, capture_output=True)
+        # one offload bundle per translation unit, concatenated (each padded): split at the magic
+        blob, magic = fat.read_bytes(), b"__CLANG_OFFLOAD_BUNDLE__"
+        starts = [m.start() for m in re.finditer(re.escape(magic), blob)]
+        names, sizes = [], []
+        for i, a in enumerate(starts):
+            piece, co = tmp_path / f"{tag}.{i}.bundle", tmp_path / f"{tag}.{i}.co"
+            piece.write_bytes(blob[a:starts[i + 1] if i + 1 < len(starts) else len(blob)])
+            subprocess.run([str(tools[1]), "--unbundle", "--type=o", f"--input={piece}", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950",
+                            f"--output={co}"], check=True, capture_output=True)
+            if co.stat().st_size == 0:
+                continue  # a translation unit without device code (the C-ABI file)
+            notes = subprocess.run([str(tools[2]), "--notes", str(co)], check=True, capture_output=True, text=True).stdout
+            names += [l.split(":", 1)[1].strip() for l in notes.splitlines() if l.strip().startswith(".name:")]
+            sizes += [int(l.split(":", 1)[1]) for l in notes.splitlines() if ".private_segment_fixed_size:" in l]
+        assert len(sizes) > least, f"{tag}: metadata not found ({len(sizes)} kernels in {len(starts)} bundles)"
+        bad = [(n, s) for n, s in zip(names[: len(sizes)], sizes) if s != 0]
+        assert not any(s for s in sizes), f"{tag}: {sum(1 for s in sizes if s)} kernel(s) use scratch: {bad[:3]}"
 
 
 def test_makefile_and_build_py_use_the_same_flags():
