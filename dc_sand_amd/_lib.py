@@ -33,6 +33,12 @@ B16 = 0
 B32 = 1
 
 
+class Timespec(ctypes.Structure):
+    """``struct timespec`` (x86-64 Linux: two longs) -- the reference kernels' time arguments."""
+
+    _fields_ = [("tv_sec", ctypes.c_long), ("tv_nsec", ctypes.c_long)]
+
+
 class DcsError(RuntimeError):
     """A non-zero status from the C-ABI (the reference's GPU_ERRCHK prints and
     exits, ``common/Utils.cpp:8-16``; here it raises)."""
@@ -51,6 +57,7 @@ SIGNATURES = [
     ("dcs_bf_default_params", c_int, [POINTER(CParams)]),
     ("dcs_bf_output_bytes", c_int, [POINTER(CParams), c_int, c_uint32, POINTER(c_size_t)]),
     ("dcs_bf_delta_times", c_int, [POINTER(CParams), c_uint64, c_uint32, POINTER(c_float)]),
+    ("dcs_bf_ts_diff", c_int, [POINTER(Timespec), POINTER(Timespec), POINTER(c_float)]),
     ("dcs_bf_simulate_input", c_int, [POINTER(CParams), _VP]),
     ("dcs_device_count", c_int, [POINTER(c_int)]),
     ("dcs_device_set", c_int, [c_int]),
@@ -79,12 +86,18 @@ SIGNATURES = [
     ("dcs_bf_set_delays_from_global", c_int, [_VP, _VP, c_uint32, c_uint32, _VP]),
     ("dcs_bf_generate", c_int, [_VP, c_int, c_int, c_uint64, c_uint32, _VP, c_size_t, _VP]),
     ("dcs_bf_generate_slab", c_int, [_VP, c_int, c_uint64, c_uint32, c_uint32, c_uint32, _VP, c_size_t, _VP]),
+    ("dcs_bf_generate_dt", c_int, [_VP, c_int, c_int, POINTER(c_float), c_uint32, _VP, c_size_t, _VP]),
+    ("dcs_bf_generate_slab_dt", c_int, [_VP, c_int, POINTER(c_float), c_uint32, c_uint32, c_uint32, _VP, c_size_t, _VP]),
+    ("dcs_bf_generate_at", c_int, [_VP, c_int, c_int, POINTER(Timespec), POINTER(Timespec), c_uint32, _VP, c_size_t, _VP]),
+    ("dcs_bf_generate_and_beamform_dt", c_int, [_VP, POINTER(c_float), c_uint32, _VP, c_size_t, _VP, c_size_t, _VP]),
     ("dcs_bf_set_tuning", c_int, [_VP, _VP]),
     ("dcs_bf_autotune", c_int, [_VP, c_int, _VP, c_size_t, _VP, _VP]),
     ("dcs_bf_generate_and_beamform", c_int, [_VP, c_uint64, c_uint32, _VP, c_size_t, _VP, c_size_t, _VP]),
     ("dcs_bf_gpu_utilisation", c_int, [POINTER(CParams), c_float, POINTER(c_float)]),
     ("dcs_bf_stream_begin", c_int, [_VP, c_int, c_uint32, c_uint32, _VP, c_size_t, _VP, POINTER(_VP)]),
     ("dcs_bf_stream_tick", c_int, [_VP, c_uint64, _VP]),
+    ("dcs_bf_stream_tick_dt", c_int, [_VP, c_float, _VP]),
+    ("dcs_bf_stream_tick_at", c_int, [_VP, POINTER(Timespec), POINTER(Timespec), _VP]),
     ("dcs_bf_stream_end", c_int, [_VP]),
 ]
 

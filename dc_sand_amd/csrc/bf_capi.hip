@@ -43,6 +43,9 @@ bool params_ok(const dcs_bf_params *p)
     if ((uint64_t)p->nr_stations * (uint64_t)p->nr_beams > 0x7fffffffull) return false;
     if (!(p->sampling_period > 0.0f) || !std::isfinite(p->sampling_period)) return false;
     if (p->fft_size < 1) return false;
+    // dcs_bf_gpu_utilisation divides by both (BeamformerCoefficientTest.cu:426-429)
+    if (p->nr_samples_per_channel < 1 || p->accumulations_before_new_coeffs < 1) return false;
+    if (!(p->adc_sample_rate > 0.0) || !std::isfinite(p->adc_sample_rate)) return false;
     const float D = p->sampling_period * (float)p->nr_channels;
     if (!(D >= 0x1p-40f && D <= 0x1p40f)) return false; // dcs_div_const's proven range
     return true;
@@ -188,6 +191,23 @@ int dcs_bf_delta_times(const dcs_bf_params *p, uint64_t t0, uint32_t nt, float *
         volatile float dt = 0.0f + q;
         dt_out[i] = dt;
     }
+    return DCS_OK;
+}
+
+int dcs_bf_ts_diff(const struct timespec *first, const struct timespec *last, float *dt_out)
+{
+    if (!first || !last || !dt_out) return DCS_ERR_INVALID_ARGUMENT;
+    // BeamformerCoefficientTest.cu:12-18, operation by operation (fp32, one rounding each):
+    //   float time_difference = (float)last.tv_sec - (float)first.tv_sec;
+    //   long nanosec_difference = last.tv_nsec - first.tv_nsec;
+    //   time_difference += (float)nanosec_difference / 1e9f;
+    volatile float fl = (float)last->tv_sec, ff = (float)first->tv_sec;
+    volatile float secs = fl - ff;
+    const long nanosec_difference = last->tv_nsec - first->tv_nsec;
+    volatile float num = (float)nanosec_difference;
+    volatile float q = num / 1e9f;
+    volatile float dt = secs + q;
+    *dt_out = dt;
     return DCS_OK;
 }
 
@@ -569,15 +589,31 @@ int launch_form(dcs_bf_context *c, bool out16, const float *dt_dev, float dt0, u
                      : launch_rows(c, out16, dt_dev, dt0, nt, c0, nc, d_out, stream);
 }
 
-// Stage dt[t0..t0+n) through a pinned slot into device memory on `stream`.
-int stage_dt(dcs_bf_context *c, uint64_t t0, uint32_t n, hipStream_t stream, const float **dt_dev)
+// Where a call's fDeltaTime values come from: the verifier's recipe for time indices
+// [t0, t0 + nt) (dcs_bf_delta_times), or the caller's own values (dcs_bf_generate_dt / _at).
+struct dt_source {
+    const float *values; // nullptr: derive from the time index
+    uint64_t t0;
+};
+
+int fill_dt(const dcs_bf_context *c, const dt_source &src, uint32_t off, uint32_t n, float *dst)
+{
+    if (src.values) {
+        std::memcpy(dst, src.values + off, (size_t)n * sizeof(float));
+        return DCS_OK;
+    }
+    return dcs_bf_delta_times(&c->p, src.t0 + off, n, dst);
+}
+
+// Stage n fDeltaTime values through a pinned slot into device memory on `stream`.
+int stage_dt(dcs_bf_context *c, const dt_source &src, uint32_t off, uint32_t n, hipStream_t stream, const float **dt_dev)
 {
     const int slot = c->dt_next;
     c->dt_next = (c->dt_next + 1) % kDtSlots;
     if (c->dt_used[slot]) DCS_TRY(hipEventSynchronize(c->dt_ev[slot])); // slot still in flight?
     float *h = c->h_dt + (size_t)slot * kDtSlotFloats;
     float *d = c->d_dt + (size_t)slot * kDtSlotFloats;
-    int st = dcs_bf_delta_times(&c->p, t0, n, h);
+    int st = fill_dt(c, src, off, n, h);
     if (st != DCS_OK) return st;
     DCS_TRY(hipMemcpyAsync(d, h, (size_t)n * sizeof(float), hipMemcpyHostToDevice, stream));
     DCS_TRY(hipEventRecord(c->dt_ev[slot], stream));
@@ -586,10 +622,8 @@ int stage_dt(dcs_bf_context *c, uint64_t t0, uint32_t n, hipStream_t stream, con
     return DCS_OK;
 }
 
-} // namespace
-
-int dcs_bf_generate_slab(dcs_bf_context *c, int bitwidth, uint64_t t0, uint32_t nt, uint32_t c0, uint32_t nc,
-                         void *d_out, size_t out_bytes, void *stream)
+int generate_slab_impl(dcs_bf_context *c, int bitwidth, const dt_source &src, uint32_t nt, uint32_t c0, uint32_t nc,
+                       void *d_out, size_t out_bytes, void *stream)
 {
     if (!c || (!d_out && nt && nc)) return DCS_ERR_INVALID_ARGUMENT;
     DCS_CHECK_DEVICE(c);
@@ -608,16 +642,16 @@ int dcs_bf_generate_slab(dcs_bf_context *c, int bitwidth, uint64_t t0, uint32_t 
         int st;
         if (n == 1) {
             float dt;
-            if ((st = dcs_bf_delta_times(&c->p, t0 + done, 1, &dt)) != DCS_OK) return st;
+            if ((st = fill_dt(c, src, done, 1, &dt)) != DCS_OK) return st;
             st = launch_form(c, out16, nullptr, dt, 1, c0, nc, dst, s);
         } else if ((c->tune.form == 0 || c->tune.form == 1) && n <= kDtInline) {
             // tiled form, few time steps: their dt values ride in the kernel arguments (no copy in front)
             float dts[kDtInline];
-            if ((st = dcs_bf_delta_times(&c->p, t0 + done, n, dts)) != DCS_OK) return st;
+            if ((st = fill_dt(c, src, done, n, dts)) != DCS_OK) return st;
             st = launch_tiled(c, out16, nullptr, dts[0], n, c0, nc, dst, s, dts);
         } else {
             const float *dt_dev = nullptr;
-            if ((st = stage_dt(c, t0 + done, n, s, &dt_dev)) != DCS_OK) return st;
+            if ((st = stage_dt(c, src, done, n, s, &dt_dev)) != DCS_OK) return st;
             st = launch_form(c, out16, dt_dev, 0.0f, n, c0, nc, dst, s);
         }
         if (st != DCS_OK) return st;
@@ -626,8 +660,8 @@ int dcs_bf_generate_slab(dcs_bf_context *c, int bitwidth, uint64_t t0, uint32_t 
     return DCS_OK;
 }
 
-int dcs_bf_generate(dcs_bf_context *c, int kernel, int bitwidth, uint64_t t0, uint32_t nt, void *d_out,
-                    size_t out_bytes, void *stream)
+int generate_impl(dcs_bf_context *c, int kernel, int bitwidth, const dt_source &src, uint32_t nt, void *d_out,
+                  size_t out_bytes, void *stream)
 {
     if (!c) return DCS_ERR_INVALID_ARGUMENT;
     DCS_CHECK_DEVICE(c);
@@ -642,7 +676,7 @@ int dcs_bf_generate(dcs_bf_context *c, int kernel, int bitwidth, uint64_t t0, ui
     if (!c->table_set) return DCS_ERR_NOT_READY;
     const uint32_t C = (uint32_t)c->p.nr_channels;
     if (kernel == DCS_BF_MULTIPLE_CHANNELS_AND_TIMESTAMPS)
-        return dcs_bf_generate_slab(c, bitwidth, t0, nt, 0, C, d_out, out_bytes, stream);
+        return generate_slab_impl(c, bitwidth, src, nt, 0, C, d_out, out_bytes, stream);
 
     const bool out16 = bitwidth == DCS_BF_B16;
     const size_t step_bytes = (size_t)C * c->n_pairs * (out16 ? 4 : 8);
@@ -651,7 +685,7 @@ int dcs_bf_generate(dcs_bf_context *c, int kernel, int bitwidth, uint64_t t0, ui
     // host time loop, one launch per time step: BeamformerCoefficientTest.cu:230-250
     for (uint32_t i = 0; i < nt; i++) {
         float dt;
-        int st = dcs_bf_delta_times(&c->p, t0 + i, 1, &dt);
+        int st = fill_dt(c, src, i, 1, &dt);
         if (st != DCS_OK) return st;
         char *dst = static_cast<char *>(d_out) + (size_t)i * step_bytes;
         if (kernel == DCS_BF_NAIVE) {
@@ -673,12 +707,68 @@ int dcs_bf_generate(dcs_bf_context *c, int kernel, int bitwidth, uint64_t t0, ui
     return DCS_OK;
 }
 
-int dcs_bf_generate_and_beamform(dcs_bf_context *c, uint64_t t0, uint32_t nt, const int8_t *d_antenna,
-                                 size_t antenna_bytes, float *d_beams, size_t beams_bytes, void *stream)
+// dt[i] = ts_diff(ref, cur[i]) for a (current, reference) pair per time step.
+int dts_from_timespecs(const struct timespec *cur, const struct timespec *ref, uint32_t nt, float *dt)
+{
+    for (uint32_t i = 0; i < nt; i++) {
+        const int st = dcs_bf_ts_diff(ref, &cur[i], &dt[i]);
+        if (st != DCS_OK) return st;
+    }
+    return DCS_OK;
+}
+
+} // namespace
+
+int dcs_bf_generate_slab(dcs_bf_context *c, int bitwidth, uint64_t t0, uint32_t nt, uint32_t c0, uint32_t nc,
+                         void *d_out, size_t out_bytes, void *stream)
+{
+    return generate_slab_impl(c, bitwidth, dt_source{nullptr, t0}, nt, c0, nc, d_out, out_bytes, stream);
+}
+
+int dcs_bf_generate(dcs_bf_context *c, int kernel, int bitwidth, uint64_t t0, uint32_t nt, void *d_out,
+                    size_t out_bytes, void *stream)
+{
+    return generate_impl(c, kernel, bitwidth, dt_source{nullptr, t0}, nt, d_out, out_bytes, stream);
+}
+
+int dcs_bf_generate_dt(dcs_bf_context *c, int kernel, int bitwidth, const float *dt, uint32_t nt, void *d_out,
+                       size_t out_bytes, void *stream)
+{
+    if (!dt && nt) return DCS_ERR_INVALID_ARGUMENT;
+    return generate_impl(c, kernel, bitwidth, dt_source{dt, 0}, nt, d_out, out_bytes, stream);
+}
+
+int dcs_bf_generate_slab_dt(dcs_bf_context *c, int bitwidth, const float *dt, uint32_t nt, uint32_t c0, uint32_t nc,
+                            void *d_out, size_t out_bytes, void *stream)
+{
+    if (!dt && nt) return DCS_ERR_INVALID_ARGUMENT;
+    return generate_slab_impl(c, bitwidth, dt_source{dt, 0}, nt, c0, nc, d_out, out_bytes, stream);
+}
+
+int dcs_bf_generate_at(dcs_bf_context *c, int kernel, int bitwidth, const struct timespec *cur,
+                       const struct timespec *ref, uint32_t nt, void *d_out, size_t out_bytes, void *stream)
+{
+    if ((!cur && nt) || !ref) return DCS_ERR_INVALID_ARGUMENT;
+    float small[kDtInline];
+    float *dt = small;
+    if (nt > kDtInline) {
+        dt = new (std::nothrow) float[nt];
+        if (!dt) return (int)hipErrorOutOfMemory;
+    }
+    int st = dts_from_timespecs(cur, ref, nt, dt);
+    // the values are consumed (kernel arguments / pinned staging slots) before generate_impl returns
+    if (st == DCS_OK) st = generate_impl(c, kernel, bitwidth, dt_source{dt, 0}, nt, d_out, out_bytes, stream);
+    if (dt != small) delete[] dt;
+    return st;
+}
+
+namespace {
+int beamform_impl(dcs_bf_context *c, const dt_source &src, uint32_t nt, const int8_t *d_antenna,
+                  size_t antenna_bytes, float *d_beams, size_t beams_bytes, void *stream)
 {
     if (!c || (nt && (!d_antenna || !d_beams))) return DCS_ERR_INVALID_ARGUMENT;
     DCS_CHECK_DEVICE(c);
-    if ((t0 % 16u) || (nt % 16u)) return DCS_ERR_INVALID_ARGUMENT; // INTERNAL_TIME_SAMPLES, BeamformerParameters.h:51
+    if (nt % 16u) return DCS_ERR_INVALID_ARGUMENT; // INTERNAL_TIME_SAMPLES, BeamformerParameters.h:51
     if (!c->table_set) return DCS_ERR_NOT_READY;
     const uint32_t A = (uint32_t)c->p.nr_stations, B = (uint32_t)c->p.nr_beams, C = (uint32_t)c->p.nr_channels;
     // BeamformerCoefficientTest.cu:25-26 (sizes of the antenna and beam tensors)
@@ -697,7 +787,7 @@ int dcs_bf_generate_and_beamform(dcs_bf_context *c, uint64_t t0, uint32_t nt, co
     for (uint32_t done = 0; done < nt;) {
         const uint32_t n = (nt - done) < chunk ? (nt - done) : chunk;
         const float *dt_dev = nullptr;
-        int st = stage_dt(c, t0 + done, n, s, &dt_dev);
+        int st = stage_dt(c, src, done, n, s, &dt_dev);
         if (st != DCS_OK) return st;
         DCS_TRY(hipMemsetAsync(c->d_flags, 0, (size_t)n * sizeof(uint32_t), s));
         bf_bform_terms_args ta;
@@ -734,6 +824,21 @@ int dcs_bf_generate_and_beamform(dcs_bf_context *c, uint64_t t0, uint32_t nt, co
         done += n;
     }
     return DCS_OK;
+}
+} // namespace
+
+int dcs_bf_generate_and_beamform(dcs_bf_context *c, uint64_t t0, uint32_t nt, const int8_t *d_antenna,
+                                 size_t antenna_bytes, float *d_beams, size_t beams_bytes, void *stream)
+{
+    if (t0 % 16u) return DCS_ERR_INVALID_ARGUMENT; // whole 16-sample blocks
+    return beamform_impl(c, dt_source{nullptr, t0}, nt, d_antenna, antenna_bytes, d_beams, beams_bytes, stream);
+}
+
+int dcs_bf_generate_and_beamform_dt(dcs_bf_context *c, const float *dt, uint32_t nt, const int8_t *d_antenna,
+                                    size_t antenna_bytes, float *d_beams, size_t beams_bytes, void *stream)
+{
+    if (!dt && nt) return DCS_ERR_INVALID_ARGUMENT;
+    return beamform_impl(c, dt_source{dt, 0}, nt, d_antenna, antenna_bytes, d_beams, beams_bytes, stream);
 }
 
 int dcs_bf_autotune(dcs_bf_context *c, int bitwidth, void *d_out, size_t out_bytes, void *stream,
@@ -944,14 +1049,11 @@ int dcs_bf_stream_begin(dcs_bf_context *c, int bitwidth, uint32_t c0, uint32_t n
     return DCS_OK;
 }
 
-int dcs_bf_stream_tick(dcs_bf_stream *s, uint64_t t, const dcs_delay_vals *new_table)
+int dcs_bf_stream_tick_dt(dcs_bf_stream *s, float dt, const dcs_delay_vals *new_table)
 {
     if (!s) return DCS_ERR_INVALID_ARGUMENT;
     dcs_bf_context *c = s->ctx;
     DCS_CHECK_DEVICE(c);
-    float dt;
-    int st = dcs_bf_delta_times(&c->p, t, 1, &dt);
-    if (st != DCS_OK) return st;
     if (new_table) {
         // stage through pinned memory into the IDLE table buffer; replays already
         // queued keep reading the current one (their arguments are baked in)
@@ -976,6 +1078,25 @@ int dcs_bf_stream_tick(dcs_bf_stream *s, uint64_t t, const dcs_delay_vals *new_t
     np.kernelParams = params;
     DCS_TRY(hipGraphExecKernelNodeSetParams(s->exec, s->node, &np));
     return (int)hipGraphLaunch(s->exec, s->stream);
+}
+
+int dcs_bf_stream_tick(dcs_bf_stream *s, uint64_t t, const dcs_delay_vals *new_table)
+{
+    if (!s) return DCS_ERR_INVALID_ARGUMENT;
+    float dt;
+    const int st = dcs_bf_delta_times(&s->ctx->p, t, 1, &dt);
+    if (st != DCS_OK) return st;
+    return dcs_bf_stream_tick_dt(s, dt, new_table);
+}
+
+int dcs_bf_stream_tick_at(dcs_bf_stream *s, const struct timespec *cur, const struct timespec *ref,
+                          const dcs_delay_vals *new_table)
+{
+    if (!s) return DCS_ERR_INVALID_ARGUMENT;
+    float dt;
+    const int st = dcs_bf_ts_diff(ref, cur, &dt);
+    if (st != DCS_OK) return st;
+    return dcs_bf_stream_tick_dt(s, dt, new_table);
 }
 
 int dcs_bf_stream_end(dcs_bf_stream *s)

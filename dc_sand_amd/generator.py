@@ -30,6 +30,26 @@ def delta_times(params: BeamformerParameters, t0: int, nt: int) -> np.ndarray:
     return out
 
 
+def ts_diff(first, last) -> np.float32:
+    """``ts_diff`` of the reference verifier (``BeamformerCoefficientTest.cu:12-18``); ``first`` / ``last`` are
+    ``(tv_sec, tv_nsec)`` pairs.  Host only."""
+    a, b = _lib.Timespec(int(first[0]), int(first[1])), _lib.Timespec(int(last[0]), int(last[1]))
+    out = c_float(0.0)
+    check(_lib.lib().dcs_bf_ts_diff(byref(a), byref(b), byref(out)), "dcs_bf_ts_diff")
+    return np.float32(out.value)
+
+
+def _dt_array(dt) -> np.ndarray:
+    return np.ascontiguousarray(np.atleast_1d(np.asarray(dt, dtype=np.float32)))
+
+
+def _timespecs(times):
+    arr = (_lib.Timespec * len(times))()
+    for i, (sec, nsec) in enumerate(times):
+        arr[i].tv_sec, arr[i].tv_nsec = int(sec), int(nsec)
+    return arr
+
+
 def simulate_input(params: BeamformerParameters) -> np.ndarray:
     """The reference's linear-ramp table (``BeamformerCoefficientTest.cu:185-196``)."""
     out = np.empty(params.n_pairs, dtype=delay_vals_dtype)
@@ -97,6 +117,45 @@ class SteeringCoefficientGenerator:
             _lib.lib().dcs_bf_generate_slab(c_void_p(self._h), int(bitwidth), int(t0), int(nt), int(c0), int(nc),
                                             c_void_p(int(d_out)), int(out_bytes), _s(stream)),
             "dcs_bf_generate_slab",
+        )
+
+    def generate_dt(self, d_out, out_bytes: int, dt, kernel: int = MULTIPLE_CHANNELS_AND_TIMESTAMPS, bitwidth: int = B32,
+                    stream=None) -> None:
+        """As :meth:`generate` with fDeltaTime of every time step given by value (``dcs_bf_generate_dt``)."""
+        a = _dt_array(dt)
+        check(
+            _lib.lib().dcs_bf_generate_dt(c_void_p(self._h), int(kernel), int(bitwidth), a.ctypes.data_as(ctypes.POINTER(c_float)),
+                                          a.size, c_void_p(int(d_out)), int(out_bytes), _s(stream)),
+            "dcs_bf_generate_dt",
+        )
+
+    def generate_slab_dt(self, d_out, out_bytes: int, c0: int, nc: int, dt, bitwidth: int = B32, stream=None) -> None:
+        a = _dt_array(dt)
+        check(
+            _lib.lib().dcs_bf_generate_slab_dt(c_void_p(self._h), int(bitwidth), a.ctypes.data_as(ctypes.POINTER(c_float)), a.size,
+                                               int(c0), int(nc), c_void_p(int(d_out)), int(out_bytes), _s(stream)),
+            "dcs_bf_generate_slab_dt",
+        )
+
+    def generate_at(self, d_out, out_bytes: int, current_times, reference_time, kernel: int = MULTIPLE_CHANNELS_AND_TIMESTAMPS,
+                    bitwidth: int = B32, stream=None) -> None:
+        """The reference kernels' own time arguments (``struct timespec sCurrentTime, sRefTime``,
+        ``BeamformerKernels.cuh:38-42``): one ``(tv_sec, tv_nsec)`` per time step and one reference."""
+        cur = _timespecs(list(current_times))
+        ref = _lib.Timespec(int(reference_time[0]), int(reference_time[1]))
+        check(
+            _lib.lib().dcs_bf_generate_at(c_void_p(self._h), int(kernel), int(bitwidth), cur, byref(ref), len(cur),
+                                          c_void_p(int(d_out)), int(out_bytes), _s(stream)),
+            "dcs_bf_generate_at",
+        )
+
+    def generate_and_beamform_dt(self, d_antenna, antenna_bytes: int, d_beams, beams_bytes: int, dt, stream=None) -> None:
+        a = _dt_array(dt)
+        check(
+            _lib.lib().dcs_bf_generate_and_beamform_dt(c_void_p(self._h), a.ctypes.data_as(ctypes.POINTER(c_float)), a.size,
+                                                       c_void_p(int(d_antenna)), int(antenna_bytes), c_void_p(int(d_beams)),
+                                                       int(beams_bytes), _s(stream)),
+            "dcs_bf_generate_and_beamform_dt",
         )
 
     def generate_and_beamform(self, d_antenna, antenna_bytes: int, d_beams, beams_bytes: int, t0: int = 0,
@@ -173,6 +232,25 @@ class CoefficientStream:
                 raise ValueError("bad delay table")
             ptr = c_void_p(new_table.ctypes.data)
         check(_lib.lib().dcs_bf_stream_tick(c_void_p(self._h), int(t), ptr), "dcs_bf_stream_tick")
+
+    def _table_ptr(self, new_table):
+        if new_table is None:
+            return c_void_p(None), None
+        new_table = np.ascontiguousarray(new_table)
+        if new_table.dtype != delay_vals_dtype or new_table.size != self._gen.params.n_pairs:
+            raise ValueError("bad delay table")
+        return c_void_p(new_table.ctypes.data), new_table
+
+    def tick_dt(self, dt: float, new_table: np.ndarray | None = None) -> None:
+        """A tick at model time ``dt`` seconds after the reference time (``dcs_bf_stream_tick_dt``)."""
+        ptr, keep = self._table_ptr(new_table)
+        check(_lib.lib().dcs_bf_stream_tick_dt(c_void_p(self._h), float(np.float32(dt)), ptr), "dcs_bf_stream_tick_dt")
+
+    def tick_at(self, current_time, reference_time, new_table: np.ndarray | None = None) -> None:
+        ptr, keep = self._table_ptr(new_table)
+        cur = _lib.Timespec(int(current_time[0]), int(current_time[1]))
+        ref = _lib.Timespec(int(reference_time[0]), int(reference_time[1]))
+        check(_lib.lib().dcs_bf_stream_tick_at(c_void_p(self._h), byref(cur), byref(ref), ptr), "dcs_bf_stream_tick_at")
 
     def end(self) -> None:
         if self._h:

@@ -25,6 +25,7 @@
 
 #include <stddef.h>
 #include <stdint.h>
+#include <time.h> /* struct timespec: the reference kernels' time arguments */
 
 #ifdef __cplusplus
 extern "C" {
@@ -32,7 +33,7 @@ extern "C" {
 /* the libraries are built -fvisibility=hidden: only what this header declares is exported */
 #pragma GCC visibility push(default)
 
-#define DCS_BF_ABI_VERSION 1
+#define DCS_BF_ABI_VERSION 2
 
 /* ---- status codes ------------------------------------------------------- */
 #define DCS_OK 0
@@ -100,6 +101,16 @@ int dcs_bf_output_bytes(const struct dcs_bf_params *p, int bitwidth, uint32_t nt
  * the dt every kernel variant uses. */
 int dcs_bf_delta_times(const struct dcs_bf_params *p, uint64_t t0, uint32_t nt, float *dt_out);
 
+/* ts_diff(), BCT.cu:12-18, operation by operation:
+ *   (float)last.tv_sec - (float)first.tv_sec + (float)(last.tv_nsec - first.tv_nsec) / 1e9f
+ * -- including what that text does not do: no nanosecond carry (the TODOs at BCT.cu:232,244,296 and
+ * BeamformerKernels.cu:24,82; harmless, the difference is signed) and seconds converted to fp32 BEFORE
+ * the subtraction, so epoch-sized tv_sec (> 2^24) lose their low bits -- use a monotonic clock or a
+ * recent reference, as the reference does (CLOCK_MONOTONIC, BCT.cu:59-69).  The reference's kernels
+ * subtract the integer seconds first (BeamformerKernels.cu:25-27, 83-85); the two agree whenever both
+ * tv_sec < 2^24.  Host only. */
+int dcs_bf_ts_diff(const struct timespec *first, const struct timespec *last, float *dt_out);
+
 /* simulate_input(), BCT.cu:185-196: the reference's linear-ramp table for
  * n = nr_stations*nr_beams entries.  Host only. */
 int dcs_bf_simulate_input(const struct dcs_bf_params *p, struct dcs_delay_vals *table_out);
@@ -137,7 +148,14 @@ typedef struct dcs_bf_context dcs_bf_context;
 /* Owns the device delay table (double-buffered) and the per-launch dt slots for
  * the given shape on the current device; replaces the buffer ownership of
  * BeamformerCoeffTest's ctor/dtor (BCT.cu:73-87,93-109).  Output buffers belong
- * to the caller.  Shape guards return DCS_ERR_INVALID_ARGUMENT. */
+ * to the caller.  Shape guards return DCS_ERR_INVALID_ARGUMENT.
+ *
+ * STREAM RULE: a context is used from ONE stream at a time.  Its device-side scratch (the two
+ * delay-table buffers, the fDeltaTime staging slots of launches longer than 256 time steps, the
+ * terms table of the rows form and of the fused kernel) is reused by later calls without
+ * cross-stream events, exactly as BeamformerCoeffTest's buffers are used from the null stream
+ * only.  To move a context to another stream, synchronise the old stream first; concurrent
+ * streams need one context each (a context is a few MiB). */
 int dcs_bf_create(const struct dcs_bf_params *p, dcs_bf_context **ctx);
 int dcs_bf_destroy(dcs_bf_context *ctx);
 
@@ -168,6 +186,21 @@ int dcs_bf_generate(dcs_bf_context *ctx, int kernel, int bitwidth, uint64_t t0, 
 int dcs_bf_generate_slab(dcs_bf_context *ctx, int bitwidth, uint64_t t0, uint32_t nt,
                          uint32_t c0, uint32_t nc, void *d_out, size_t out_bytes, void *stream);
 
+/* The same launches with the TIME given by the caller instead of derived from a time index --
+ * what the reference's kernels take (struct timespec sCurrentTime, sRefTime by value:
+ * BeamformerKernels.cuh:38-42, 81-86; arithmetic BeamformerKernels.cu:25-27, 83-85; the verifier's
+ * ts_diff BCT.cu:12-18, :320).  dcs_bf_generate(t0, nt) is the special case
+ * cur[i] = ref + (long)((t0+i)*SAMPLING_PERIOD*1e9f*FFT_SIZE) ns (BCT.cu:296-300).
+ *   _dt: fDeltaTime of each of the nt time steps by value (host array, consumed before return);
+ *   _at: cur[i] (nt entries) and one reference time; fDeltaTime[i] = dcs_bf_ts_diff(ref, &cur[i]).
+ * Output layout, kernel / bitwidth rules and capturability as dcs_bf_generate. */
+int dcs_bf_generate_dt(dcs_bf_context *ctx, int kernel, int bitwidth, const float *dt, uint32_t nt,
+                       void *d_out, size_t out_bytes, void *stream);
+int dcs_bf_generate_slab_dt(dcs_bf_context *ctx, int bitwidth, const float *dt, uint32_t nt, uint32_t c0,
+                            uint32_t nc, void *d_out, size_t out_bytes, void *stream);
+int dcs_bf_generate_at(dcs_bf_context *ctx, int kernel, int bitwidth, const struct timespec *cur,
+                       const struct timespec *ref, uint32_t nt, void *d_out, size_t out_bytes, void *stream);
+
 /* run_kernel(), COMBINED_COEFF_GEN_AND_BEAMFORMER_SINGLE_CHANNEL branch (BCT.cu:259-262;
  * kernel BeamformerKernels.cu:192-367, doc BeamformerKernels.cuh:95-162; verifier
  * BCT.cu:363-414) -- SURVEY.md section 8 f1, generalised from the reference's
@@ -182,6 +215,10 @@ int dcs_bf_generate_slab(dcs_bf_context *ctx, int bitwidth, uint64_t t0, uint32_
  * No coefficient tensor is materialised. */
 int dcs_bf_generate_and_beamform(dcs_bf_context *ctx, uint64_t t0, uint32_t nt, const int8_t *d_antenna,
                                  size_t antenna_bytes, float *d_beams, size_t beams_bytes, void *stream);
+
+/* The same with fDeltaTime of each of the nt samples by value (nt a multiple of 16). */
+int dcs_bf_generate_and_beamform_dt(dcs_bf_context *ctx, const float *dt, uint32_t nt, const int8_t *d_antenna,
+                                    size_t antenna_bytes, float *d_beams, size_t beams_bytes, void *stream);
 
 /* Launch-geometry knobs (all 0 / NULL = library defaults; DESIGN.md "launch
  * geometry").  Two forms of the MULTIPLE_CHANNELS_AND_TIMESTAMPS generator
@@ -241,6 +278,12 @@ typedef struct dcs_bf_stream dcs_bf_stream;
 int dcs_bf_stream_begin(dcs_bf_context *ctx, int bitwidth, uint32_t c0, uint32_t nc, void *d_out,
                         size_t out_bytes, void *stream, dcs_bf_stream **s);
 int dcs_bf_stream_tick(dcs_bf_stream *s, uint64_t t, const struct dcs_delay_vals *new_table);
+/* A tick at an arbitrary model time: fDeltaTime by value, or (current, reference) as the reference's
+ * kernels take them (BeamformerKernels.cuh:38-42).  BASELINE configs[4]'s "200 us cadence" is
+ * tick_dt(k * 200e-6f): model time and wall time advance together. */
+int dcs_bf_stream_tick_dt(dcs_bf_stream *s, float dt, const struct dcs_delay_vals *new_table);
+int dcs_bf_stream_tick_at(dcs_bf_stream *s, const struct timespec *cur, const struct timespec *ref,
+                          const struct dcs_delay_vals *new_table);
 int dcs_bf_stream_end(dcs_bf_stream *s);
 
 #pragma GCC visibility pop

@@ -120,14 +120,15 @@ static int g_trig_reading = 0;
 void dcs_oracle_set_trig_reading(int reading) { g_trig_reading = reading == 1 ? 1 : 0; }
 int dcs_oracle_get_trig_reading(void) { return g_trig_reading; }
 
-/* BeamformerCoefficientTest.cu:319-328 */
-void dcs_oracle_coeff(const struct dcs_oracle_params *p,
-                      struct dcs_oracle_delay_vals d, float fDeltaTime,
-                      size_t c, float *re, float *im)
+/* BeamformerCoefficientTest.cu:319-328, with the reading of cos(float) passed in (the threaded
+ * comparison below evaluates both readings without touching the process-wide switch). */
+static void coeff_reading(const struct dcs_oracle_params *p,
+                          struct dcs_oracle_delay_vals d, float fDeltaTime,
+                          size_t c, int reading, float *re, float *im)
 {
     float fRotation = dcs_oracle_rotation(p, d, fDeltaTime, c);
     float fSteeringCoeffCorrectReal, fSteeringCoeffCorrectImag;
-    if (g_trig_reading == 1) {
+    if (reading == 1) {
         fSteeringCoeffCorrectReal = cosf(fRotation);
         fSteeringCoeffCorrectImag = sinf(fRotation);
     } else {
@@ -136,6 +137,14 @@ void dcs_oracle_coeff(const struct dcs_oracle_params *p,
     }
     *re = fSteeringCoeffCorrectReal;
     *im = fSteeringCoeffCorrectImag;
+}
+
+/* BeamformerCoefficientTest.cu:319-328 */
+void dcs_oracle_coeff(const struct dcs_oracle_params *p,
+                      struct dcs_oracle_delay_vals d, float fDeltaTime,
+                      size_t c, float *re, float *im)
+{
+    coeff_reading(p, d, fDeltaTime, c, g_trig_reading, re, im);
 }
 
 static const struct timespec k_ref_zero = {0, 0};
@@ -165,6 +174,45 @@ double dcs_oracle_generate(const struct dcs_oracle_params *p,
         }
     }
     return now_s() - start;
+}
+
+/* BeamformerCoefficientTest.cu:308-333 with fDeltaTime (:320) of each time step given by the
+ * caller instead of derived from the time index (:296-300): the verifier for a caller that holds
+ * real (current, reference) times, as the reference's kernels take them
+ * (BeamformerKernels.cuh:38-42, 81-86). */
+void dcs_oracle_generate_dt(const struct dcs_oracle_params *p,
+                            const struct dcs_oracle_delay_vals *delays,
+                            const float *dt, size_t nt, size_t c0, size_t nc,
+                            float *out)
+{
+    const size_t NR_STATIONS = (size_t)p->nr_stations;
+    const size_t NR_BEAMS = (size_t)p->nr_beams;
+    for (size_t t = 0; t < nt; t++) {
+        float fDeltaTime = dt[t];
+        for (size_t c = c0; c < c0 + nc; c++) {
+            for (size_t a = 0; a < NR_STATIONS; a++) {
+                for (size_t b = 0; b < NR_BEAMS; b++) {
+                    size_t iAntBeamOrdering = a * NR_BEAMS + b;
+                    size_t ulCoeffIndex = 2 * ((t * nc + (c - c0)) * NR_STATIONS * NR_BEAMS + iAntBeamOrdering);
+                    dcs_oracle_coeff(p, delays[iAntBeamOrdering], fDeltaTime, c,
+                                     &out[ulCoeffIndex], &out[ulCoeffIndex + 1]);
+                }
+            }
+        }
+    }
+}
+
+/* The same with fDeltaTime = ts_diff(ref, cur[t]) (BeamformerCoefficientTest.cu:320). */
+void dcs_oracle_generate_at(const struct dcs_oracle_params *p,
+                            const struct dcs_oracle_delay_vals *delays,
+                            const struct timespec *cur, struct timespec ref,
+                            size_t nt, size_t c0, size_t nc, float *out)
+{
+    const size_t step = 2 * nc * (size_t)p->nr_stations * (size_t)p->nr_beams;
+    for (size_t t = 0; t < nt; t++) {
+        float fDeltaTime = dcs_oracle_ts_diff(ref, cur[t]);
+        dcs_oracle_generate_dt(p, delays, &fDeltaTime, 1, c0, nc, out + t * step);
+    }
 }
 
 static inline uint32_t f32_bits(float f)
@@ -271,6 +319,82 @@ uint32_t dcs_oracle_max_ulp(const float *got, const float *expect, size_t n,
     return mx;
 }
 
+/* BeamformerCoefficientTest.cu:294-337 + :348-357 fused: the expected coefficient of every element
+ * of got[nt][nc][A*B][2] is generated and compared on the fly (no expected tensor is stored), the
+ * channel range split over threads.  hist[d] counts elements at ULP distance d = 0, 1, 2 and
+ * hist[3] those beyond. */
+struct cmp_job {
+    const struct dcs_oracle_params *p;
+    const struct dcs_oracle_delay_vals *delays;
+    const float *dt;
+    size_t nt, c0, nc, cb, ce; /* this thread: channels [cb, ce) of the slab [c0, c0+nc) */
+    const float *got;
+    int reading;
+    uint64_t hist[4];
+    uint32_t max_ulp;
+    int64_t first_over;
+};
+
+static void *cmp_worker(void *arg)
+{
+    struct cmp_job *j = (struct cmp_job *)arg;
+    const size_t n = (size_t)j->p->nr_stations * (size_t)j->p->nr_beams;
+    for (size_t t = 0; t < j->nt; t++) {
+        const float fDeltaTime = j->dt[t];
+        for (size_t c = j->cb; c < j->ce; c++) {
+            const size_t base = 2 * ((t * j->nc + (c - j->c0)) * n);
+            for (size_t i = 0; i < n; i++) {
+                float e[2];
+                coeff_reading(j->p, j->delays[i], fDeltaTime, c, j->reading, &e[0], &e[1]);
+                for (int k = 0; k < 2; k++) {
+                    const uint32_t d = dcs_oracle_ulp_diff(j->got[base + 2 * i + k], e[k]);
+                    j->hist[d > 3 ? 3 : d]++;
+                    if (d > j->max_ulp) j->max_ulp = d;
+                    if (d > 1 && j->first_over < 0) j->first_over = (int64_t)(base + 2 * i + k);
+                }
+            }
+        }
+    }
+    return NULL;
+}
+
+double dcs_oracle_compare_generated(const struct dcs_oracle_params *p,
+                                    const struct dcs_oracle_delay_vals *delays,
+                                    const float *dt, size_t nt, size_t c0, size_t nc,
+                                    const float *got, int nthreads, int reading,
+                                    uint64_t hist[4], uint32_t *max_ulp, int64_t *first_over_1ulp)
+{
+    if (nthreads < 1) nthreads = 1;
+    if ((size_t)nthreads > nc && nc > 0) nthreads = (int)nc;
+    struct cmp_job *jobs = calloc((size_t)nthreads, sizeof(*jobs));
+    pthread_t *th = calloc((size_t)nthreads, sizeof(*th));
+    double start = now_s();
+    size_t per = nc / (size_t)nthreads, rem = nc % (size_t)nthreads, c = c0;
+    for (int i = 0; i < nthreads; i++) {
+        size_t cnt = per + ((size_t)i < rem ? 1 : 0);
+        jobs[i] = (struct cmp_job){p, delays, dt, nt, c0, nc, c, c + cnt, got, reading == 1 ? 1 : 0, {0, 0, 0, 0}, 0, -1};
+        c += cnt;
+        if (i > 0) pthread_create(&th[i], NULL, cmp_worker, &jobs[i]);
+    }
+    cmp_worker(&jobs[0]);
+    for (int i = 1; i < nthreads; i++) pthread_join(th[i], NULL);
+    uint32_t mx = 0;
+    int64_t first = -1;
+    uint64_t h[4] = {0, 0, 0, 0};
+    for (int i = 0; i < nthreads; i++) {
+        for (int k = 0; k < 4; k++) h[k] += jobs[i].hist[k];
+        if (jobs[i].max_ulp > mx) mx = jobs[i].max_ulp;
+        if (jobs[i].first_over >= 0 && (first < 0 || jobs[i].first_over < first)) first = jobs[i].first_over;
+    }
+    double secs = now_s() - start;
+    free(jobs);
+    free(th);
+    if (hist) memcpy(hist, h, sizeof(h));
+    if (max_ulp) *max_ulp = mx;
+    if (first_over_1ulp) *first_over_1ulp = first;
+    return secs;
+}
+
 /* BeamformerKernels.cu:153-177 (kernel a3's arithmetic), on the host. */
 void dcs_oracle_device_variant_a3(const struct dcs_oracle_params *p,
                                   const struct dcs_oracle_delay_vals *delays,
@@ -307,9 +431,9 @@ void dcs_oracle_simulate_antenna_data(int8_t *out, size_t nbytes)
 }
 
 /* BeamformerCoefficientTest.cu:294-337 (ordering :311) + :363-414 */
-void dcs_oracle_beamform(const struct dcs_oracle_params *p,
-                         const struct dcs_oracle_delay_vals *delays, size_t nt,
-                         const int8_t *pi8InAntData, float *pfCorrectBeams)
+static void beamform_impl(const struct dcs_oracle_params *p,
+                          const struct dcs_oracle_delay_vals *delays, const float *dt, size_t nt,
+                          const int8_t *pi8InAntData, float *pfCorrectBeams)
 {
     const size_t NR_CHANNELS = (size_t)p->nr_channels;
     const size_t NR_STATIONS = (size_t)p->nr_stations;
@@ -320,7 +444,7 @@ void dcs_oracle_beamform(const struct dcs_oracle_params *p,
         for (size_t t_ex = 0; t_ex < NR_SAMPLES_PER_CHANNEL / INTERNAL_TIME_SAMPLES; t_ex++) {
             for (size_t t_in = 0; t_in < INTERNAL_TIME_SAMPLES; t_in++) {
                 const size_t t = t_ex * INTERNAL_TIME_SAMPLES + t_in;
-                float fDeltaTime = dcs_oracle_delta_time(p, t, k_ref_zero);
+                float fDeltaTime = dt ? dt[t] : dcs_oracle_delta_time(p, t, k_ref_zero);
                 for (size_t b = 0; b < NR_BEAMS; b++) {
                     size_t iBeamIndex = c * NR_SAMPLES_PER_CHANNEL * NR_BEAMS + t_ex * NR_BEAMS * INTERNAL_TIME_SAMPLES + b * INTERNAL_TIME_SAMPLES + t_in;
                     float fBeamSumReal = 0;
@@ -341,6 +465,21 @@ void dcs_oracle_beamform(const struct dcs_oracle_params *p,
             }
         }
     }
+}
+
+void dcs_oracle_beamform(const struct dcs_oracle_params *p,
+                         const struct dcs_oracle_delay_vals *delays, size_t nt,
+                         const int8_t *pi8InAntData, float *pfCorrectBeams)
+{
+    beamform_impl(p, delays, NULL, nt, pi8InAntData, pfCorrectBeams);
+}
+
+/* The same with fDeltaTime of each of the nt samples given (cf. dcs_oracle_generate_dt). */
+void dcs_oracle_beamform_dt(const struct dcs_oracle_params *p,
+                            const struct dcs_oracle_delay_vals *delays, const float *dt, size_t nt,
+                            const int8_t *pi8InAntData, float *pfCorrectBeams)
+{
+    beamform_impl(p, delays, dt, nt, pi8InAntData, pfCorrectBeams);
 }
 
 /* IEEE binary16 round-to-nearest-even of an fp32 (what __floats2half2_rn does

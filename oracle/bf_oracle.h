@@ -94,6 +94,19 @@ double dcs_oracle_generate(const struct dcs_oracle_params *p,
                            size_t t0, size_t nt, size_t c0, size_t nc,
                            float *out);
 
+/* BeamformerCoefficientTest.cu:308-333 with fDeltaTime (:320) of each of the nt time steps given
+ * by the caller: out[(t*nc + (c-c0))*A*B + a*B + b][2]. */
+void dcs_oracle_generate_dt(const struct dcs_oracle_params *p,
+                            const struct dcs_oracle_delay_vals *delays,
+                            const float *dt, size_t nt, size_t c0, size_t nc,
+                            float *out);
+/* ... with fDeltaTime[t] = ts_diff(ref, cur[t]) (:320): the reference kernels' own time arguments
+ * (BeamformerKernels.cuh:38-42, 81-86). */
+void dcs_oracle_generate_at(const struct dcs_oracle_params *p,
+                            const struct dcs_oracle_delay_vals *delays,
+                            const struct timespec *cur, struct timespec ref,
+                            size_t nt, size_t c0, size_t nc, float *out);
+
 /* Same loop, no output tensor: returns an order-independent checksum (sum of
  * the fp32 bit patterns, mod 2^64) over the same elements and the seconds
  * spent.  nthreads > 1 splits the channel range over pthreads (the reference
@@ -113,6 +126,20 @@ int64_t dcs_oracle_compare(const float *got, const float *expect, size_t n,
 uint32_t dcs_oracle_ulp_diff(float a, float b);
 uint32_t dcs_oracle_max_ulp(const float *got, const float *expect, size_t n,
                             uint32_t limit, uint64_t *n_over, int64_t *first_over);
+
+/* verify_output() without the expected tensor (BeamformerCoefficientTest.cu:294-337 fused with
+ * :348-357): every element of got[nt][nc][A*B][2] (channels [c0, c0+nc), fDeltaTime per time step
+ * in dt[]) is compared with the coefficient generated on the fly; the channel range is split over
+ * nthreads.  reading: 0 = (float)cos((double)x), 1 = cosf(x) (see dcs_oracle_set_trig_reading; the
+ * process-wide switch is not touched).  hist[d] = number of fp32 elements at ULP distance d
+ * (d = 0, 1, 2; hist[3]: more), *max_ulp, *first_over_1ulp = first flat index with d > 1 or -1.
+ * Returns the seconds spent.  This is what lets the full-size configs be compared in EVERY element,
+ * as the reference's verifier does. */
+double dcs_oracle_compare_generated(const struct dcs_oracle_params *p,
+                                    const struct dcs_oracle_delay_vals *delays,
+                                    const float *dt, size_t nt, size_t c0, size_t nc,
+                                    const float *got, int nthreads, int reading,
+                                    uint64_t hist[4], uint32_t *max_ulp, int64_t *first_over_1ulp);
 
 /* Restatement of the reference's DEVICE arithmetic, kernel a3
  * (BeamformerKernels.cu:153-177): dt = t*Ts*FFT in fp32, integer
@@ -137,6 +164,10 @@ void dcs_oracle_simulate_antenna_data(int8_t *out, size_t nbytes);
 void dcs_oracle_beamform(const struct dcs_oracle_params *p,
                          const struct dcs_oracle_delay_vals *delays, size_t nt,
                          const int8_t *antenna_data, float *out);
+
+void dcs_oracle_beamform_dt(const struct dcs_oracle_params *p,
+                            const struct dcs_oracle_delay_vals *delays, const float *dt, size_t nt,
+                            const int8_t *antenna_data, float *out);
 
 /* fp16 (f2): IEEE binary16 round-to-nearest-even of an fp32, as
  * __floats2half2_rn does per element (BeamformerKernels.cu:113,182). */

@@ -69,6 +69,12 @@ def lib() -> ctypes.CDLL:
         L.dcs_oracle_generate.restype = c_double
         L.dcs_oracle_generate_checksum.argtypes = [P, c_void_p, c_size_t, c_size_t, c_size_t, c_size_t, c_int, POINTER(c_uint64)]
         L.dcs_oracle_generate_checksum.restype = c_double
+        L.dcs_oracle_generate_dt.argtypes = [P, c_void_p, c_void_p, c_size_t, c_size_t, c_size_t, c_void_p]
+        L.dcs_oracle_generate_at.argtypes = [P, c_void_p, c_void_p, Timespec, c_size_t, c_size_t, c_size_t, c_void_p]
+        L.dcs_oracle_beamform_dt.argtypes = [P, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]
+        L.dcs_oracle_compare_generated.argtypes = [P, c_void_p, c_void_p, c_size_t, c_size_t, c_size_t, c_void_p, c_int, c_int,
+                                                   POINTER(c_uint64 * 4), POINTER(c_uint32), POINTER(c_int64)]
+        L.dcs_oracle_compare_generated.restype = c_double
         L.dcs_oracle_compare.argtypes = [c_void_p, c_void_p, c_size_t, c_float]
         L.dcs_oracle_compare.restype = c_int64
         L.dcs_oracle_ulp_diff.argtypes = [c_float, c_float]
@@ -144,6 +150,49 @@ def generate(p: OracleParams, delays: np.ndarray, t0=0, nt=1, c0=0, nc=None) -> 
     return out
 
 
+def ts_diff(first, last) -> np.float32:
+    """BeamformerCoefficientTest.cu:12-18; (tv_sec, tv_nsec) pairs."""
+    return np.float32(lib().dcs_oracle_ts_diff(Timespec(*first), Timespec(*last)))
+
+
+def generate_dt(p: OracleParams, delays: np.ndarray, dt, c0=0, nc=None) -> np.ndarray:
+    """Expected coefficients [nt][nc][A][B][2] for fDeltaTime values given by the caller."""
+    nc = p.nr_channels - c0 if nc is None else nc
+    dt = np.ascontiguousarray(np.atleast_1d(np.asarray(dt, dtype=np.float32)))
+    delays = np.ascontiguousarray(delays, dtype=delay_vals_dtype)
+    assert delays.size == p.nr_stations * p.nr_beams
+    out = np.empty((dt.size, nc, p.nr_stations, p.nr_beams, 2), dtype=np.float32)
+    lib().dcs_oracle_generate_dt(byref(p), c_void_p(delays.ctypes.data), c_void_p(dt.ctypes.data), dt.size, c0, nc, c_void_p(out.ctypes.data))
+    return out
+
+
+def generate_at(p: OracleParams, delays: np.ndarray, current_times, reference_time, c0=0, nc=None) -> np.ndarray:
+    """Expected coefficients for (current, reference) times as the reference kernels take them."""
+    nc = p.nr_channels - c0 if nc is None else nc
+    cur = (Timespec * len(current_times))(*[Timespec(int(s), int(ns)) for s, ns in current_times])
+    delays = np.ascontiguousarray(delays, dtype=delay_vals_dtype)
+    out = np.empty((len(current_times), nc, p.nr_stations, p.nr_beams, 2), dtype=np.float32)
+    lib().dcs_oracle_generate_at(byref(p), c_void_p(delays.ctypes.data), cur, Timespec(int(reference_time[0]), int(reference_time[1])),
+                                 len(current_times), c0, nc, c_void_p(out.ctypes.data))
+    return out
+
+
+def compare_generated(p: OracleParams, delays: np.ndarray, dt, c0: int, nc: int, got: np.ndarray, nthreads: int = 1, reading: int = 0):
+    """Every element of ``got`` ([nt][nc][A][B][2] fp32, C-contiguous; any buffer of that many floats) against
+    the verifier, generated on the fly over ``nthreads`` threads.  Returns dict(hist=[n0, n1, n2, n_more],
+    max_ulp, first_over_1ulp, seconds)."""
+    dt = np.ascontiguousarray(np.atleast_1d(np.asarray(dt, dtype=np.float32)))
+    delays = np.ascontiguousarray(delays, dtype=delay_vals_dtype)
+    assert got.dtype == np.float32 and got.flags["C_CONTIGUOUS"]
+    assert got.size == dt.size * nc * p.nr_stations * p.nr_beams * 2
+    hist = (c_uint64 * 4)()
+    mx = c_uint32(0)
+    first = c_int64(-1)
+    secs = lib().dcs_oracle_compare_generated(byref(p), c_void_p(delays.ctypes.data), c_void_p(dt.ctypes.data), dt.size, int(c0), int(nc),
+                                              c_void_p(got.ctypes.data), int(nthreads), int(reading), byref(hist), byref(mx), byref(first))
+    return dict(hist=[int(v) for v in hist], max_ulp=int(mx.value), first_over_1ulp=int(first.value), seconds=float(secs))
+
+
 def generate_checksum(p: OracleParams, delays: np.ndarray, t0=0, nt=1, c0=0, nc=None, nthreads=1):
     """(seconds, checksum): sum of the fp32 bit patterns mod 2^64."""
     nc = p.nr_channels - c0 if nc is None else nc
@@ -199,6 +248,18 @@ def beamform(p: OracleParams, delays_beam_major: np.ndarray, nt: int, antenna_da
     assert ant.size == p.nr_channels * nt * p.nr_stations * 2
     out = np.empty((p.nr_channels, nt // 16, p.nr_beams, 16, 2), dtype=np.float32)
     lib().dcs_oracle_beamform(byref(p), c_void_p(delays.ctypes.data), nt, c_void_p(ant.ctypes.data), c_void_p(out.ctypes.data))
+    return out
+
+
+def beamform_dt(p: OracleParams, delays_beam_major: np.ndarray, dt, antenna_data: np.ndarray) -> np.ndarray:
+    dt = np.ascontiguousarray(np.atleast_1d(np.asarray(dt, dtype=np.float32)))
+    nt = dt.size
+    assert nt % 16 == 0
+    delays = np.ascontiguousarray(delays_beam_major, dtype=delay_vals_dtype)
+    ant = np.ascontiguousarray(antenna_data, dtype=np.int8)
+    assert ant.size == p.nr_channels * nt * p.nr_stations * 2
+    out = np.empty((p.nr_channels, nt // 16, p.nr_beams, 16, 2), dtype=np.float32)
+    lib().dcs_oracle_beamform_dt(byref(p), c_void_p(delays.ctypes.data), c_void_p(dt.ctypes.data), nt, c_void_p(ant.ctypes.data), c_void_p(out.ctypes.data))
     return out
 
 

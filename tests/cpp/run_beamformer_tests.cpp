@@ -8,6 +8,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <ctime>
 #include <string>
 #include <vector>
 
@@ -23,9 +24,10 @@
         }                                                                                    \
     } // = GPU_ERRCHK, common/Utils.hpp:8
 
-struct CoeffTest { // BeamformerCoeffTest for the three coefficient kernels, fp32
+struct CoeffTest { // BeamformerCoeffTest for the three coefficient kernels, b32 or b16
     dcs_bf_params p;
     int kernel;
+    int bitwidth;
     float tol;
     dcs_bf_context *ctx = nullptr;
     dcs_delay_vals *hDelays = nullptr;
@@ -36,10 +38,13 @@ struct CoeffTest { // BeamformerCoeffTest for the three coefficient kernels, fp3
     float htod_ms = 0, kernel_ms = 0, dtoh_ms = 0;
     uint32_t max_ulp = 0;
 
-    CoeffTest(float tolerance, int kernelOption) : kernel(kernelOption), tol(tolerance)
+    struct timespec refTime; // m_sReferenceTime_ns, BeamformerCoefficientTest.cu:59-69 (CLOCK_MONOTONIC)
+
+    CoeffTest(float tolerance, int kernelOption, int bitWidth) : kernel(kernelOption), bitwidth(bitWidth), tol(tolerance)
     {
         DCS_ERRCHK(dcs_bf_default_params(&p));
-        DCS_ERRCHK(dcs_bf_output_bytes(&p, DCS_BF_B32, (uint32_t)p.nr_samples_per_channel, &coeffBytes));
+        clock_gettime(CLOCK_MONOTONIC, &refTime);
+        DCS_ERRCHK(dcs_bf_output_bytes(&p, bitwidth, (uint32_t)p.nr_samples_per_channel, &coeffBytes));
         const size_t n = (size_t)p.nr_stations * p.nr_beams;
         DCS_ERRCHK(dcs_host_alloc((void **)&hDelays, n * sizeof(dcs_delay_vals)));
         DCS_ERRCHK(dcs_host_alloc((void **)&hCoeffs, coeffBytes));
@@ -57,7 +62,22 @@ struct CoeffTest { // BeamformerCoeffTest for the three coefficient kernels, fp3
     void transfer_HtoD() { DCS_ERRCHK(dcs_bf_upload_delays(ctx, hDelays, nullptr)); }
     void run_kernel()
     {
-        DCS_ERRCHK(dcs_bf_generate(ctx, kernel, DCS_BF_B32, 0, (uint32_t)p.nr_samples_per_channel, dCoeffs, coeffBytes, nullptr));
+        const uint32_t nt = (uint32_t)p.nr_samples_per_channel;
+        if (kernel == DCS_BF_MULTIPLE_CHANNELS_AND_TIMESTAMPS) { // one launch, time derived from the index: :253-257
+            DCS_ERRCHK(dcs_bf_generate(ctx, kernel, bitwidth, 0, nt, dCoeffs, coeffBytes, nullptr));
+            return;
+        }
+        // NAIVE / MULTIPLE_CHANNELS: the reference hands its kernels (sCurrentTime, sRefTime) per time step
+        // (BeamformerCoefficientTest.cu:230-250; kernel signatures BeamformerKernels.cuh:38-42, 81-86):
+        // current = reference + time step in ns, no carry into tv_sec -- with the VERIFIER's time step (:299,
+        // fp32 product), the definition of correct.
+        std::vector<struct timespec> cur(nt);
+        for (uint32_t t = 0; t < nt; t++) {
+            long step = t * p.sampling_period * 1e9f * p.fft_size;
+            cur[t].tv_sec = refTime.tv_sec;
+            cur[t].tv_nsec = refTime.tv_nsec + step;
+        }
+        DCS_ERRCHK(dcs_bf_generate_at(ctx, kernel, bitwidth, cur.data(), &refTime, nt, dCoeffs, coeffBytes, nullptr));
     }
     void transfer_DtoH()
     {
@@ -67,10 +87,25 @@ struct CoeffTest { // BeamformerCoeffTest for the three coefficient kernels, fp3
     void verify_output()
     {
         dcs_oracle_params op = {p.nr_channels, p.nr_stations, p.nr_beams, p.sampling_period, p.fft_size};
-        std::vector<float> expect(coeffBytes / sizeof(float));
+        const size_t nElem = coeffBytes / (bitwidth == DCS_BF_B16 ? sizeof(uint16_t) : sizeof(float));
+        std::vector<float> expect(nElem);
         const double cpu_s = dcs_oracle_generate(&op, (const dcs_oracle_delay_vals *)hDelays, 0, (size_t)p.nr_samples_per_channel, 0,
                                                  (size_t)p.nr_channels, expect.data());
         std::printf("CPU took %g ms to generate correct steering coefficients.\n", cpu_s * 1e3);
+        if (bitwidth == DCS_BF_B16) {
+            // The reference skips this case and reports success (BeamformerCoefficientTest.cu:282-287).  Here:
+            // every half within 1 half-ULP of RN-even(verifier fp32) -- __floats2half2_rn of the same value.
+            const uint16_t *got = reinterpret_cast<const uint16_t *>(hCoeffs);
+            auto ordered = [](uint16_t h) { return (h & 0x8000u) ? -(int)(h & 0x7fffu) : (int)h; };
+            int worst = 0;
+            for (size_t i = 0; i < nElem; i++) {
+                const int d = std::abs(ordered(got[i]) - ordered(dcs_oracle_f32_to_f16_rn(expect[i])));
+                if (d > worst) worst = d;
+            }
+            max_ulp = (uint32_t)worst;
+            result = worst <= 1 ? 1 : -1;
+            return;
+        }
         const int64_t bad = dcs_oracle_compare(hCoeffs, expect.data(), expect.size(), tol);
         if (bad >= 0) {
             std::printf("Index: %lld. Generated Value: %g. Correct Value: %g\n", (long long)bad, hCoeffs[bad], expect[bad]);
@@ -175,11 +210,12 @@ int main()
     struct Case {
         const char *name;
         int kernel;
+        int bitwidth;
         float tol;
     } cases[] = {
-        {"Multiple Chans+Timestamps", DCS_BF_MULTIPLE_CHANNELS_AND_TIMESTAMPS, 1e-4f}, // runBeamformerTests.cpp:30
-        {"Multiple Channels", DCS_BF_MULTIPLE_CHANNELS, 1e-4f},
-        {"Naive Implementation", DCS_BF_NAIVE, 1e-4f}, // :61
+        {"Multiple Chans+Timestamps", DCS_BF_MULTIPLE_CHANNELS_AND_TIMESTAMPS, DCS_BF_B32, 1e-4f}, // runBeamformerTests.cpp:30
+        {"Multiple Channels", DCS_BF_MULTIPLE_CHANNELS, DCS_BF_B16, 1e-4f},                        // :46 (b16)
+        {"Naive Implementation", DCS_BF_NAIVE, DCS_BF_B32, 1e-4f},                                 // :61
     };
     {
         float ms = 0, mx = 0;
@@ -189,9 +225,9 @@ int main()
         }
         std::printf("%-50s kernel %.3f ms, max |beam - CPU verifier| %g (tolerance 0.1)\n", "Combined Steering Coeffs+Beamforming", ms, mx);
     }
-    std::printf("%-50s%-20s%-20s%-10s\n", "Kernel Name", "GPU Utilisation", "GPU Utilisation", "max ULP");
+    std::printf("%-50s%-20s%-20s%-10s\n", "Kernel Name", "GPU Utilisation", "GPU Utilisation", "max ULP (b16: half-ULP)");
     for (const Case &c : cases) {
-        CoeffTest t(c.tol, c.kernel);
+        CoeffTest t(c.tol, c.kernel, c.bitwidth);
         t.run_test();
         if (t.result != 1) {
             std::printf("Test failed, output data not generated correctly\n");

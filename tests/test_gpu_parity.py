@@ -66,6 +66,39 @@ def _check_float_reading(oracle, got, op, table, t0, nt, limit=1):
     return mx
 
 
+def _compare_every_element(gpu, oracle, d_buf, op, table, dt, nc_total, n_pairs, readings=(0, 1), slab_bytes=1 << 30):
+    """verify_output at full size (BeamformerCoefficientTest.cu:348-357 compares EVERY element): the device tensor
+    [nc_total][n_pairs][2] fp32 of ONE time step comes back in <= 1 GiB slabs through a pinned buffer and each slab
+    is compared with the verifier generated on the fly over all host cores (oracle.compare_generated).  Returns
+    {reading: dict(hist, max_ulp, first_over_1ulp, seconds)} accumulated over the slabs."""
+    import os
+    import time
+
+    row = n_pairs * 8
+    per = max(1, slab_bytes // row)
+    nthreads = max(1, min(64, len(os.sched_getaffinity(0))))
+    pinned = gpu.pagelocked_empty(per * n_pairs * 2, np.float32)
+    tot = {r: dict(hist=[0, 0, 0, 0], max_ulp=0, first_over_1ulp=-1, seconds=0.0) for r in readings}
+    t_copy = 0.0
+    for c0 in range(0, nc_total, per):
+        nc = min(per, nc_total - c0)
+        view = pinned[: nc * n_pairs * 2]
+        t0 = time.perf_counter()
+        gpu.memcpy_dtoh(view, int(d_buf) + c0 * row)
+        t_copy += time.perf_counter() - t0
+        for r in readings:
+            res = oracle.compare_generated(op, table, [dt], c0, nc, view, nthreads=nthreads, reading=r)
+            acc = tot[r]
+            acc["hist"] = [a + b for a, b in zip(acc["hist"], res["hist"])]
+            acc["max_ulp"] = max(acc["max_ulp"], res["max_ulp"])
+            if acc["first_over_1ulp"] < 0 and res["first_over_1ulp"] >= 0:
+                acc["first_over_1ulp"] = c0 * n_pairs * 2 + res["first_over_1ulp"]
+            acc["seconds"] += res["seconds"]
+    tot["copy_seconds"] = t_copy
+    tot["threads"] = nthreads
+    return tot
+
+
 @pytest.mark.parametrize("kernel", [0, 1, 2])
 def test_config1_4ant_2beam_1024chan(gpu, oracle, kernel):
     """BASELINE configs[0]: 4 ant x 2 beam x 1024 chan, reference ramp input."""
@@ -356,15 +389,17 @@ def test_against_committed_golden_fixtures(gpu):
             assert np.max(np.abs(gi - ei)) <= 1, (case["file"], key)
 
 
-def test_config3_full_size_sampled_channels_and_properties(gpu, oracle, probes):
-    """BASELINE configs[2] at FULL size (64 x 1024 x 32768, 16 GiB on the GPU):
-    a deterministic channel subset (c in {0, 1, C/2, C-1} and every 257th, all
-    (antenna, beam)) is copied back and compared with the oracle in ULPs; the
-    whole tensor is checked through size-independent properties on the device
-    copy (every coefficient has modulus 1; the sampled rows of a second launch
-    at another time step differ)."""
+def test_config3_full_size_every_element(gpu, oracle, probes, record_property):
+    """BASELINE configs[2] at FULL size (64 x 1024 x 32768, 16 GiB on the GPU): EVERY one of the 2^32 floats is
+    compared with the verifier, as the reference's verify_output does (BeamformerCoefficientTest.cu:348-357) --
+    <= 1 ULP under the canonical reading of cos(float), and <= 1 ULP under the float-libm reading too
+    (|fRotation| < 100 here, inside the range proven in tests/test_numerics.py), whose count of 1-ULP elements is
+    reported.  Then the size-independent properties on the device copy: unit modulus everywhere and the two
+    independent forms (tiled / rows) writing bit-identical tensors."""
+    import time
+
     from dc_sand_amd import BeamformerParameters
-    from dc_sand_amd.generator import SteeringCoefficientGenerator, simulate_input
+    from dc_sand_amd.generator import SteeringCoefficientGenerator, delta_times
 
     bp = BeamformerParameters(NR_CHANNELS=32768, NR_STATIONS=64, NR_BEAMS=1024)
     op = oracle.params_from(bp)
@@ -376,24 +411,19 @@ def test_config3_full_size_sampled_channels_and_properties(gpu, oracle, probes):
     buf = gpu.mem_alloc(nbytes)
     t = 9
     g.generate(buf, nbytes, t0=t, nt=1)
-    chans = sorted(set([0, 1, bp.NR_CHANNELS // 2, bp.NR_CHANNELS - 1] + list(range(0, bp.NR_CHANNELS, 257))))
-    row = bp.n_pairs * 8
-    host = np.empty((bp.NR_STATIONS, bp.NR_BEAMS, 2), dtype=np.float32)
-    worst = 0
-    for c in chans:
-        gpu.memcpy_dtoh(host, int(buf) + c * row)
-        exp = oracle.generate(op, table, t, 1, c, 1)
-        mx, n_over, first = oracle.max_ulp(host, exp, 1)
-        assert n_over == 0, (c, mx, first)
-        worst = max(worst, mx)
-        with oracle.trig_reading(oracle.FLOAT_LIBM):  # the verifier's other reading; |fRotation| < 100 here
-            n_over_f = oracle.max_ulp(host, oracle.generate(op, table, t, 1, c, 1), 1)[1]
-        assert n_over_f == 0, c
-        mod = np.hypot(host[..., 0].astype(np.float64), host[..., 1].astype(np.float64))
-        assert np.max(np.abs(mod - 1.0)) < 2e-7
-    assert worst <= 1
-    # sampled fraction: len(chans) / C of the tensor
-    assert len(chans) >= 128
+    gpu.synchronize()
+    t0 = time.perf_counter()
+    res = _compare_every_element(gpu, oracle, buf, op, table, delta_times(bp, t, 1)[0], bp.NR_CHANNELS, bp.n_pairs)
+    wall = time.perf_counter() - t0
+    n = bp.NR_CHANNELS * bp.n_pairs * 2
+    for r in (0, 1):
+        h = res[r]["hist"]
+        assert sum(h) == n == 2 ** 32, "sampled fraction must be 1.0"
+        assert h[2] == 0 and h[3] == 0 and res[r]["max_ulp"] <= 1, (r, res[r])
+    summary = (f"config 3, all {n} floats: reading 0 (double-then-round) {res[0]['hist'][1]} at 1 ULP, 0 beyond; reading 1 (float libm) "
+               f"{res[1]['hist'][1]} at 1 ULP, 0 beyond; {wall:.1f} s wall on {res['threads']} threads (D2H {res['copy_seconds']:.1f} s)")
+    print(summary)
+    record_property("config3_full_compare", summary)
     # whole-tensor properties on the device: unit modulus everywhere, and the two
     # independent forms (tiled / rows: different grids and index arithmetic, both
     # 64-bit) write bit-identical 16 GiB tensors
@@ -549,14 +579,15 @@ def test_fused_slow_path_with_several_channels_per_pass(gpu, oracle, A, B, C):
     g.close()
 
 
-def test_config4_one_rank_shard_at_full_size(gpu, oracle, probes):
-    """BASELINE configs[3]: 256 ant x 4096 beam x 32768 chan beam-sharded over 8 GPUs.
-    One rank's share at FULL size on this GPU (rank 3: beams [1536, 2048), 2^32
-    coefficients, 32 GiB): the slice is gathered on the device from the 16 MiB global
-    table, the tensor is sampled against the oracle's column slab, and its whole-tensor
-    properties are checked on the device."""
+def test_config4_one_rank_shard_at_full_size_every_element(gpu, oracle, probes, record_property):
+    """BASELINE configs[3]: 256 ant x 4096 beam x 32768 chan beam-sharded over 8 GPUs.  One rank's share at FULL size
+    on this GPU (rank 3: beams [1536, 2048), 2^32 coefficients, 32 GiB): the slice is gathered on the device from the
+    16 MiB global table, and EVERY one of its 2^33 floats is compared with the verifier's column slab (canonical
+    reading; byte offsets beyond 2^32); the tiled and rows forms must agree on the whole tensor."""
+    import time
+
     from dc_sand_amd import BeamformerParameters
-    from dc_sand_amd.generator import SteeringCoefficientGenerator
+    from dc_sand_amd.generator import SteeringCoefficientGenerator, delta_times
     from dc_sand_amd.sharding import beam_range, local_parameters, slice_table
 
     gp = BeamformerParameters(NR_CHANNELS=32768, NR_STATIONS=256, NR_BEAMS=4096)
@@ -574,17 +605,24 @@ def test_config4_one_rank_shard_at_full_size(gpu, oracle, probes):
     buf = gpu.mem_alloc(nbytes)
     t = 18
     g.generate(buf, nbytes, t0=t, nt=1)
+    gpu.synchronize()
     local = slice_table(glob, gp, sh)
     op = oracle.params_from(lp)
-    row = lp.n_pairs * 8
-    host = np.empty((lp.NR_STATIONS, lp.NR_BEAMS, 2), dtype=np.float32)
-    for c in (0, 1, 12345, 16384, 32767):
-        gpu.memcpy_dtoh(host, int(buf) + c * row)  # byte offsets beyond 2^32
-        exp = oracle.generate(op, local, t, 1, c, 1)
-        mx, n_over, first = oracle.max_ulp(host, exp, 1)
-        assert n_over == 0, (c, mx, first)
+    t0 = time.perf_counter()
+    res = _compare_every_element(gpu, oracle, buf, op, local, delta_times(lp, t, 1)[0], lp.NR_CHANNELS, lp.n_pairs, readings=(0,))
+    wall = time.perf_counter() - t0
+    h = res[0]["hist"]
+    assert sum(h) == 2 ** 33 and h[2] == 0 and h[3] == 0 and res[0]["max_ulp"] <= 1, res[0]
+    summary = f"config 4 rank-3 shard, all {sum(h)} floats: {h[1]} at 1 ULP, 0 beyond; {wall:.1f} s wall on {res['threads']} threads"
+    print(summary)
+    record_property("config4_shard_full_compare", summary)
     ck, dev = probes.tensor_properties(buf, nbytes)
     assert dev < 4e-7
+    g.set_tuning(form=2)
+    gpu.memset(buf, 0, nbytes)
+    g.generate(buf, nbytes, t0=t, nt=1)
+    ck2, dev2 = probes.tensor_properties(buf, nbytes)
+    assert (ck2, dev2) == (ck, dev)
     g.close()
     buf.free()
 
@@ -750,9 +788,10 @@ def test_fused_with_time_offset(gpu, oracle):
 
 
 def test_config5_streaming_at_the_200us_slab(gpu, oracle):
-    """BASELINE configs[4] at size: 64 x 1024 pairs x the 2560-channel slab that sustains the
-    200 us cadence (1.34 GB per tick), hipGraph replay, a new delay table landing between
-    ticks; sampled rows of every tick against the oracle."""
+    """BASELINE configs[4] at size: 64 x 1024 pairs x the 2560-channel slab that sustains the 200 us cadence
+    (1.34 GB per tick), hipGraph replay, MODEL time advancing 200 us per tick (dcs_bf_stream_tick_dt, and
+    dcs_bf_stream_tick_at across a seconds boundary), a new delay table landing between ticks; sampled rows of
+    every tick against the oracle evaluated at the same fDeltaTime."""
     from dc_sand_amd import BeamformerParameters
     from dc_sand_amd.generator import SteeringCoefficientGenerator
 
@@ -769,16 +808,29 @@ def test_config5_streaming_at_the_200us_slab(gpu, oracle):
     row = bp.n_pairs * 8
     host = np.empty((bp.NR_STATIONS, bp.NR_BEAMS, 2), dtype=np.float32)
     cur = 0
-    for tick, t in enumerate([7, 8, 9, 300]):
+    ref = (777, 999_500_000)  # 0.5 ms before a seconds boundary: ticks 3.. lie beyond it
+    for tick in range(1, 7):
         new = None
-        if tick == 2:
+        if tick == 3:
             cur, new = 1, tables[1]
-        st.tick(t, new)
+        if tick % 2:
+            dt = np.float32(tick * 200e-6)
+            st.tick_dt(dt, new)
+        else:
+            ns = ref[1] + tick * 200_000
+            now = (ref[0] + ns // 10 ** 9, ns % 10 ** 9)  # a normalised wall-clock reading
+            dt = oracle.ts_diff(ref, now)
+            assert abs(float(dt) - tick * 200e-6) < 1e-7
+            st.tick_at(now, ref, new)
         stream.synchronize()
         for cl in (0, 1279, nc - 1):
             gpu.memcpy_dtoh(host, int(buf) + cl * row)
-            exp = oracle.generate(op, tables[cur], t, 1, c0 + cl, 1)
-            assert oracle.max_ulp(host, exp, 1)[1] == 0, (tick, t, cl)
+            exp = oracle.generate_dt(op, tables[cur], [dt], c0 + cl, 1)
+            assert oracle.max_ulp(host, exp, 1)[1] == 0, (tick, cl)
+    st.tick(300)  # the time-index form still works on the same stream object
+    stream.synchronize()
+    gpu.memcpy_dtoh(host, int(buf))
+    assert oracle.max_ulp(host, oracle.generate(op, tables[cur], 300, 1, c0, 1), 1)[1] == 0
     st.end()
     g.close()
 
@@ -898,3 +950,124 @@ def test_generate_under_stream_capture(gpu, oracle, nt):
     hip.hipGraphDestroy(graph)
     g.close()
     buf.free()
+
+
+# ---- arbitrary-time entry points (the reference kernels take struct timespec sCurrentTime, sRefTime:
+# ---- BeamformerKernels.cuh:38-42, 81-86; the verifier's fDeltaTime is ts_diff, BeamformerCoefficientTest.cu:12-18, :320)
+OFF_GRID_DT = [0.0, 200e-6, 400e-6, 1e-3 + 3e-7, 0.123456, 1.5, -2e-4, 86400.0]  # not multiples of 819.2 us; before the reference; a day
+
+
+@pytest.mark.parametrize("kernel", [0, 1, 2])
+def test_generate_dt_off_grid_times(gpu, oracle, kernel):
+    """dcs_bf_generate_dt: fDeltaTime by value, every launch shape, against the verifier at the same fDeltaTime."""
+    from dc_sand_amd import BeamformerParameters
+    from dc_sand_amd.generator import SteeringCoefficientGenerator
+
+    bp = BeamformerParameters(NR_CHANNELS=24, NR_STATIONS=5, NR_BEAMS=13)
+    op = oracle.params_from(bp)
+    table = rand_table(bp.n_pairs, seed=71)
+    g = SteeringCoefficientGenerator(bp)
+    g.upload_delays(table)
+    dts = np.array(OFF_GRID_DT, dtype=np.float32)
+    nb = g.output_bytes(1, dts.size)
+    buf = gpu.mem_alloc(nb)
+    g.generate_dt(buf, nb, dts, kernel=kernel)
+    got = np.empty((dts.size, bp.NR_CHANNELS, bp.NR_STATIONS, bp.NR_BEAMS, 2), dtype=np.float32)
+    gpu.memcpy_dtoh(got, buf)
+    exp = oracle.generate_dt(op, table, dts)
+    _check(oracle, got, exp)
+    assert not np.array_equal(got[1], got[2])
+    if kernel != 0:  # b16 (NAIVE has no b16: BeamformerCoefficientTest.cu:40-44)
+        nb16 = g.output_bytes(0, dts.size)
+        g.generate_dt(buf, nb16, dts, kernel=kernel, bitwidth=0)
+        h16 = np.empty(got.shape, dtype=np.float16)
+        gpu.memcpy_dtoh(h16, buf)
+        assert np.array_equal(h16.view(np.uint16), got.astype(np.float16).view(np.uint16))
+    # a channel slab through dcs_bf_generate_slab_dt
+    c0, nc = 7, 9
+    nbs = dts.size * nc * bp.n_pairs * 8
+    g.generate_slab_dt(buf, nbs, c0, nc, dts)
+    gs = np.empty((dts.size, nc, bp.NR_STATIONS, bp.NR_BEAMS, 2), dtype=np.float32)
+    gpu.memcpy_dtoh(gs, buf)
+    assert np.array_equal(gs.view(np.uint32), np.ascontiguousarray(got[:, c0:c0 + nc]).view(np.uint32))
+    g.close()
+
+
+@pytest.mark.parametrize("form", [1, 2])
+def test_generate_dt_more_steps_than_ride_in_the_kernel_arguments(gpu, oracle, form):
+    """300 > 256 time steps 200 us apart (the staged fDeltaTime table), both forms; and 4100 > 4096 (two launches)."""
+    from dc_sand_amd import BeamformerParameters
+    from dc_sand_amd.generator import SteeringCoefficientGenerator
+
+    bp = BeamformerParameters(NR_CHANNELS=5, NR_STATIONS=3, NR_BEAMS=6)
+    op = oracle.params_from(bp)
+    table = rand_table(bp.n_pairs, seed=72)
+    g = SteeringCoefficientGenerator(bp)
+    g.set_tuning(form=form)
+    g.upload_delays(table)
+    for nt in (300, 4100):
+        dts = (np.arange(nt, dtype=np.float64) * 200e-6).astype(np.float32)
+        nb = g.output_bytes(1, nt)
+        buf = gpu.mem_alloc(nb)
+        g.generate_dt(buf, nb, dts)
+        got = np.empty((nt, bp.NR_CHANNELS, bp.NR_STATIONS, bp.NR_BEAMS, 2), dtype=np.float32)
+        gpu.memcpy_dtoh(got, buf)
+        _check(oracle, got, oracle.generate_dt(op, table, dts))
+        buf.free()
+    g.close()
+
+
+@pytest.mark.parametrize("kernel", [0, 1, 2])
+def test_generate_at_timespec_pairs_across_a_seconds_boundary(gpu, oracle, kernel):
+    """dcs_bf_generate_at: (current, reference) as the reference's kernels take them.  Times 200 us apart that cross a
+    seconds boundary, given normalised (tv_sec + 1, small tv_nsec: a negative nanosecond difference) and
+    un-normalised (tv_nsec >= 1e9, as the reference's own launch loop builds them, BeamformerCoefficientTest.cu:232-236)."""
+    from dc_sand_amd import BeamformerParameters
+    from dc_sand_amd.generator import SteeringCoefficientGenerator
+
+    bp = BeamformerParameters(NR_CHANNELS=17, NR_STATIONS=4, NR_BEAMS=9)
+    op = oracle.params_from(bp)
+    table = rand_table(bp.n_pairs, seed=73)
+    g = SteeringCoefficientGenerator(bp)
+    g.upload_delays(table)
+    ref = (4242, 999_700_000)
+    steps = [k * 200_000 for k in range(8)]  # ns; the boundary falls between k = 1 and k = 2
+    unnorm = [(ref[0], ref[1] + st) for st in steps]
+    norm = [(ref[0] + (ref[1] + st) // 10 ** 9, (ref[1] + st) % 10 ** 9) for st in steps]
+    assert norm[2][0] == ref[0] + 1
+    nb = g.output_bytes(1, len(steps))
+    buf = gpu.mem_alloc(nb)
+    outs = []
+    for cur in (unnorm, norm):
+        g.generate_at(buf, nb, cur, ref, kernel=kernel)
+        got = np.empty((len(steps), bp.NR_CHANNELS, bp.NR_STATIONS, bp.NR_BEAMS, 2), dtype=np.float32)
+        gpu.memcpy_dtoh(got, buf)
+        _check(oracle, got, oracle.generate_at(op, table, cur, ref))
+        outs.append(got)
+    # the two spellings of the same instants give fDeltaTime values that agree to an fp32 rounding, not always bit for bit
+    assert np.max(np.abs(outs[0] - outs[1])) < 1e-3
+    g.close()
+
+
+def test_fused_generate_and_beamform_dt(gpu, oracle):
+    """dcs_bf_generate_and_beamform_dt: 32 samples 200 us apart."""
+    from dc_sand_amd import BeamformerParameters
+    from dc_sand_amd.generator import SteeringCoefficientGenerator
+
+    A, B, C, nt = 12, 20, 6, 32
+    bp = BeamformerParameters(NR_CHANNELS=C, NR_STATIONS=A, NR_BEAMS=B, NR_SAMPLES_PER_CHANNEL=nt)
+    op = oracle.params_from(bp)
+    table = rand_table(bp.n_pairs, seed=74)
+    ant = np.random.default_rng(10).integers(-128, 128, size=(C, nt // 16, A, 16, 2), dtype=np.int8)
+    dts = (np.arange(nt, dtype=np.float64) * 200e-6 + 0.25).astype(np.float32)
+    exp = oracle.beamform_dt(op, table, dts, ant)
+    g = SteeringCoefficientGenerator(bp)
+    g.upload_delays(table)
+    d_ant = gpu.mem_alloc(ant.nbytes)
+    gpu.memcpy_htod(d_ant, ant)
+    got = np.empty_like(exp)
+    d_beams = gpu.mem_alloc(got.nbytes)
+    g.generate_and_beamform_dt(d_ant, ant.nbytes, d_beams, got.nbytes, dts)
+    gpu.memcpy_dtoh(got, d_beams)
+    assert np.abs(got - exp).max() <= 2e-5 * A + 1e-6
+    g.close()

@@ -29,7 +29,7 @@ def test_header_symbols_are_exported_and_bound(dcs_lib):
         assert hasattr(dcs_lib, name), f"{name} declared in the header but not exported"
         assert name in bound, f"{name} has no ctypes signature in dc_sand_amd/_lib.py"
     assert bound <= set(declared)
-    assert dcs_lib.dcs_abi_version() == 1
+    assert dcs_lib.dcs_abi_version() == 2
 
 
 def test_product_library_exports_no_measurement_apparatus(dcs_lib):
@@ -102,6 +102,25 @@ def test_delta_times_and_simulate_input_equal_oracle(dcs_lib, oracle):
     assert np.array_equal(big, exp)
 
 
+def test_ts_diff_equals_the_oracles(dcs_lib, oracle):
+    """dcs_bf_ts_diff (what dcs_bf_generate_at / dcs_bf_stream_tick_at feed the kernels) is the verifier's ts_diff,
+    BeamformerCoefficientTest.cu:12-18, bit for bit -- seconds boundaries, un-normalised nanoseconds, negative
+    differences, epoch-sized seconds."""
+    from dc_sand_amd.generator import ts_diff
+
+    rng = np.random.default_rng(12)
+    cases = [((10, 0), (10, 819200)), ((10, 999_999_999), (11, 199)), ((10, 999_999_999), (10, 1_000_000_199)),
+             ((5, 0), (3, 500_000_000)), ((1_700_000_000, 0), (1_700_000_001, 0)), ((0, 0), (0, 0))]
+    for _ in range(2000):
+        s0 = int(rng.integers(0, 1 << 25))
+        cases.append(((s0, int(rng.integers(0, 10 ** 9))), (s0 + int(rng.integers(-3, 4)), int(rng.integers(0, 2 * 10 ** 9)))))
+    for first, last in cases:
+        a, b = ts_diff(first, last), oracle.ts_diff(first, last)
+        assert a.view(np.uint32) == b.view(np.uint32), (first, last, a, b)
+    out = ctypes.c_float()
+    assert dcs_lib.dcs_bf_ts_diff(None, None, byref(out)) == -1
+
+
 def test_output_bytes_and_utilisation(dcs_lib):
     from dc_sand_amd import BeamformerParameters
     from dc_sand_amd.generator import gpu_utilisation, output_bytes
@@ -129,6 +148,10 @@ def test_invalid_arguments_are_status_codes(dcs_lib):
     good = BeamformerParameters().to_c()
     assert dcs_lib.dcs_bf_output_bytes(byref(good), 7, 1, byref(n)) == _lib.DCS_ERR_INVALID_ARGUMENT
     assert dcs_lib.dcs_bf_output_bytes(None, 1, 1, byref(n)) == _lib.DCS_ERR_INVALID_ARGUMENT
+    util = (ctypes.c_float * 2)()
+    for bad_kw in (dict(NR_SAMPLES_PER_CHANNEL=0), dict(ADC_SAMPLE_RATE=0.0), dict(ACCUMULATIONS_BEFORE_NEW_COEFFS=0)):
+        badp = BeamformerParameters(**bad_kw).to_c()  # dcs_bf_gpu_utilisation divides by these
+        assert dcs_lib.dcs_bf_gpu_utilisation(byref(badp), 1.0, util) == _lib.DCS_ERR_INVALID_ARGUMENT, bad_kw
     assert b"invalid argument" in dcs_lib.dcs_error_string(_lib.DCS_ERR_INVALID_ARGUMENT)
     assert b"16 bit" in dcs_lib.dcs_error_string(_lib.DCS_ERR_UNSUPPORTED) or b"mode" in dcs_lib.dcs_error_string(_lib.DCS_ERR_UNSUPPORTED)
     assert b"another device" in dcs_lib.dcs_error_string(_lib.DCS_ERR_WRONG_DEVICE)
