@@ -110,7 +110,13 @@ struct dcs_bf_context {
     uint32_t terms_steps;   // time steps the table holds
     float *d_terms;         // [terms_steps][pairs_pad][2]; allocated on first use (ensure_terms)
     uint32_t *d_flags;      // [terms_steps][pairs_pad/64]
-    dcs_bf_tuning tune;
+    dcs_bf_tuning tune;     // the caller's explicit knobs (dcs_bf_set_tuning); 0 / -1 = not set
+    // what dcs_bf_autotune measured for this context's shape, per output width [0] = fp32, [1] = fp16;
+    // used for large launches wherever the caller has not set a knob explicitly
+    struct tuned_geom {
+        bool valid;
+        int32_t tpb, cpb, wpc; // wpc: -1 = unlimited
+    } tuned[2];
 };
 
 struct dcs_bf_stream {
@@ -418,6 +424,7 @@ int dcs_bf_set_tuning(dcs_bf_context *c, const dcs_bf_tuning *t)
         c->tune.rows_same_tile = -1;
         c->k.uDiv3Exact = c->div3_verified;
         c->k.fLowDegLimit = 500.0f;
+        c->tuned[0].valid = c->tuned[1].valid = false; // forget what dcs_bf_autotune measured, too
         return DCS_OK;
     }
     if (t->form < 0 || t->form > 2) return DCS_ERR_INVALID_ARGUMENT;
@@ -447,27 +454,76 @@ int dcs_bf_set_tuning(dcs_bf_context *c, const dcs_bf_tuning *t)
 
 namespace {
 
-// Defaults: see DESIGN.md "launch geometry" (measured on MI355X at
-// 64 x 1024 x 32768, profiles/r01_geometry_sweep.md).  The write rate the HBM
-// system sustains falls with the number of stores a wave issues before it
-// retires, so the fp32 walk is kept SHORT; the optimum is sharp and moves with
-// the arithmetic's speed (dcs_bf_autotune re-measures it for a given shape):
-//   fp32: 1 tile x 12 channels per workgroup (3 stores per wave), at most 6 workgroups per CU, nontemporal;
-//   fp16: 1 tile x 128 channels per workgroup (VALU-bound: amortise the set-up).
-void pick_geometry(const dcs_bf_context *c, bool out16, uint32_t nc, uint32_t nt, int *tpb, uint32_t *cpb, bool *ntstore)
+// Launch geometry of the tiled form for ONE launch of nt time steps x nc channels (DESIGN.md "launch
+// geometry"; measured on MI355X: profiles/r01_geometry_sweep.md, profiles/r02_autotune.md).  The write
+// rate the HBM system sustains falls with the number of stores a wave issues before it retires, so the
+// fp32 walk is kept SHORT; the optimum is flat within ~2 % around these points for every shape swept:
+//   fp32, plenty of work: 1 tile x 12 channels per workgroup (3 stores per wave), at most 6 workgroups per CU;
+//   fp32, rows of >= 2048 tiles (>= 2 MiB: one row outlasts the resident workgroups): 10 channels, no limit;
+//   fp32, <= 32 MiB of output in > 1024 workgroups (launch-bound): 2 tiles x 16 channels (fewer, fatter workgroups);
+//   fp16 (VALU-bound): 1 tile x 128 channels to amortise the per-workgroup set-up, halved while that
+//         leaves the chip fewer than 2048 workgroups (down to 16);
+//   any launch whose workgroups are all resident at once (<= 8 per CU): no residency limit -- the unused
+//         dynamic LDS behind it costs a small launch 1-2 us and buys nothing there.
+// Order of precedence per knob: the caller's explicit dcs_bf_set_tuning value, then (large launches
+// only) what dcs_bf_autotune measured for this context, then the rule above.
+struct bf_geom {
+    int tpb;
+    uint32_t cpb;
+    int wpc; // 0 = unlimited
+    bool ntstore;
+};
+
+uint64_t tiled_blocks(uint32_t n_pairs, bool out16, int tpb, uint32_t cpb, uint32_t nc, uint32_t nt)
 {
-    (void)nc;
-    (void)nt;
-    *tpb = c->tune.tiles_per_block ? c->tune.tiles_per_block : 1;
-    *ntstore = c->tune.nontemporal < 0 ? true : c->tune.nontemporal != 0;
-    *cpb = c->tune.chan_per_block ? (uint32_t)c->tune.chan_per_block : (out16 ? 128u : 12u);
+    const uint32_t ppb = 64u * (out16 ? 4u : 2u) * (uint32_t)tpb;
+    return (uint64_t)((n_pairs + ppb - 1) / ppb) * ((nc + cpb - 1) / cpb) * nt;
 }
 
-// Workgroups per CU: 0 = the default (fp32: 6, which also flattens the optimum; fp16: no limit), -1 = no limit.
-int pick_wg_per_cu(const dcs_bf_context *c, bool out16)
+bf_geom shape_default_geometry(const dcs_bf_context *c, bool out16, uint32_t nc, uint32_t nt)
 {
-    if (c->tune.wg_per_cu != 0) return c->tune.wg_per_cu > 0 ? c->tune.wg_per_cu : 0;
-    return out16 ? 0 : 6;
+    constexpr uint64_t kResident = 256u * 8u; // workgroups of 256 threads the chip holds at once
+    bf_geom g;
+    g.ntstore = true;
+    g.tpb = 1;
+    if (out16) {
+        g.cpb = 128u;
+        g.wpc = 0;
+        while (g.cpb > 16u && tiled_blocks(c->n_pairs, true, 1, g.cpb, nc, nt) < kResident) g.cpb >>= 1;
+        return g;
+    }
+    g.cpb = 12u;
+    g.wpc = 6;
+    const uint32_t tiles = (c->n_pairs + 127u) / 128u;
+    if (tiles >= 2048u) {
+        g.cpb = 10u;
+        g.wpc = 0;
+    }
+    const uint64_t bytes = (uint64_t)nt * nc * c->n_pairs * 8u;
+    if (bytes <= (32ull << 20) && tiled_blocks(c->n_pairs, false, 1, g.cpb, nc, nt) > 1024u) {
+        g.tpb = 2;
+        g.cpb = 16u;
+        g.wpc = 0;
+    }
+    return g;
+}
+
+bf_geom pick_geometry(const dcs_bf_context *c, bool out16, uint32_t nc, uint32_t nt)
+{
+    constexpr uint64_t kResident = 256u * 8u;
+    bf_geom g = shape_default_geometry(c, out16, nc, nt);
+    const dcs_bf_context::tuned_geom &t = c->tuned[out16 ? 1 : 0];
+    if (t.valid && tiled_blocks(c->n_pairs, out16, t.tpb, (uint32_t)t.cpb, nc, nt) > kResident) {
+        g.tpb = t.tpb;
+        g.cpb = (uint32_t)t.cpb;
+        g.wpc = t.wpc > 0 ? t.wpc : 0;
+    }
+    if (c->tune.tiles_per_block) g.tpb = c->tune.tiles_per_block;
+    if (c->tune.chan_per_block) g.cpb = (uint32_t)c->tune.chan_per_block;
+    if (c->tune.nontemporal >= 0) g.ntstore = c->tune.nontemporal != 0;
+    if (c->tune.wg_per_cu != 0) g.wpc = c->tune.wg_per_cu > 0 ? c->tune.wg_per_cu : 0;
+    else if (tiled_blocks(c->n_pairs, out16, g.tpb, g.cpb, nc, nt) <= kResident) g.wpc = 0;
+    return g;
 }
 
 // Dynamic LDS a launch asks for so that exactly k workgroups fit a CU's 160 KiB (gfx950): the
@@ -495,18 +551,16 @@ int prepare_tiled(dcs_bf_context *c, bool out16, const float *dt_dev, float dt0,
     a.nc = nc;
     a.nt = nt;
     a.k = c->k;
-    int tpb;
-    uint32_t cpb;
-    bool ntstore;
-    pick_geometry(c, out16, nc, nt, &tpb, &cpb, &ntstore);
-    a.chan_per_block = cpb;
+    const bf_geom g = pick_geometry(c, out16, nc, nt);
+    const int tpb = g.tpb;
+    const bool ntstore = g.ntstore;
+    a.chan_per_block = g.cpb;
     a.xcd_remap = c->tune.xcd_remap > 0 ? 1u : 0u;
 #ifdef DCS_PROBES
     a.pace = (uint32_t)c->tune.probe_pace;
 #endif
     const int st = (int)bf_prepare_tiled(a, out16, tpb | (c->tune.probe_nomath ? 0x100 : 0) | (c->tuning_now ? 0x200 : 0), ntstore, l);
-    const int wpc = pick_wg_per_cu(c, out16);
-    if (st == DCS_OK && wpc > 0) l->shared = lds_pad_for(wpc, out16, tpb);
+    if (st == DCS_OK && g.wpc > 0) l->shared = lds_pad_for(g.wpc, out16, tpb);
     return st;
 }
 
@@ -855,25 +909,56 @@ int dcs_bf_autotune(dcs_bf_context *c, int bitwidth, void *d_out, size_t out_byt
     if (nc64 == 0) return DCS_ERR_INVALID_ARGUMENT;
     const uint32_t nc = (uint32_t)nc64;
     hipStream_t s = as_stream(stream);
+    dcs_bf_context::tuned_geom &slot = c->tuned[out16 ? 1 : 0];
+
+    auto report = [&]() {
+        if (!chosen) return;
+        *chosen = c->tune;
+        chosen->form = 1;
+        chosen->tiles_per_block = slot.tpb;
+        chosen->chan_per_block = slot.cpb;
+        chosen->wg_per_cu = slot.wpc;
+        chosen->nontemporal = 1;
+    };
+    if (slot.valid) { // measured before for this context (shape) and width: dcs_bf_set_tuning(ctx, NULL) forgets it
+        report();
+        return DCS_OK;
+    }
 
     struct cand { int tpb, cpb, wpc; double best_ms; }; // wpc: workgroups per CU (-1 = unlimited)
-    // fp32: the short walks around the optimum, unlimited and with 6-7 workgroups per CU (fewer waves in flight
+    // fp32: the short walks around the optimum, unlimited and with 5-7 workgroups per CU (fewer waves in flight
     // keep the store stream closer to address order: the best point moves to a slightly longer walk and is
     // ~1 % higher, profiles/r01_store_patterns.md); fp16: VALU-bound, long walks
-    static const int k32[][3] = {{1, 8, -1}, {1, 10, -1}, {1, 11, -1}, {1, 12, -1}, {1, 13, -1}, {1, 14, -1}, {1, 15, -1},
-                                 {1, 16, -1}, {1, 18, -1}, {1, 20, -1}, {1, 24, -1}, {2, 8, -1}, {2, 12, -1}, {4, 8, -1},
+    static const int k32[][3] = {{1, 8, -1}, {1, 10, -1}, {1, 11, -1}, {1, 12, -1}, {1, 13, -1}, {1, 14, -1}, {1, 16, -1},
+                                 {1, 20, -1}, {2, 6, -1}, {2, 8, -1}, {2, 12, -1}, {2, 16, -1}, {4, 4, -1}, {4, 8, -1},
                                  {1, 10, 7}, {1, 11, 7}, {1, 12, 7}, {1, 13, 7}, {1, 14, 7}, {1, 11, 6}, {1, 12, 6}, {1, 13, 6}, {1, 14, 6},
                                  {1, 14, 5}, {1, 16, 5}};
-    static const int k16[][3] = {{1, 32, -1}, {1, 64, -1}, {1, 96, -1}, {1, 128, -1}, {1, 192, -1}, {1, 256, -1},
-                                 {2, 64, -1}, {4, 32, -1}, {4, 48, -1}};
+    static const int k16[][3] = {{1, 16, -1}, {1, 32, -1}, {1, 64, -1}, {1, 96, -1}, {1, 128, -1}, {1, 192, -1}, {1, 256, -1},
+                                 {1, 128, 7}, {1, 192, 6}, {2, 64, -1}, {4, 32, -1}, {4, 48, -1}};
     const int(*tab)[3] = out16 ? k16 : k32;
-    const int ncand = out16 ? (int)(sizeof(k16) / sizeof(k16[0])) : (int)(sizeof(k32) / sizeof(k32[0]));
+    int ncand = out16 ? (int)(sizeof(k16) / sizeof(k16[0])) : (int)(sizeof(k32) / sizeof(k32[0]));
     cand cands[32];
-    static_assert(sizeof(k32) / sizeof(k32[0]) <= 32 && sizeof(k16) / sizeof(k16[0]) <= 32, "cands[] too small");
+    static_assert(sizeof(k32) / sizeof(k32[0]) < 32 && sizeof(k16) / sizeof(k16[0]) < 32, "cands[] too small");
     for (int i = 0; i < ncand; i++) cands[i] = {tab[i][0], tab[i][1], tab[i][2], 1e30};
+    // the library's own choice for this shape always takes part (and wins ties, below)
+    const bf_geom dflt = shape_default_geometry(c, out16, nc, 1);
+    int i_default = -1;
+    for (int i = 0; i < ncand; i++)
+        if (cands[i].tpb == dflt.tpb && cands[i].cpb == (int)dflt.cpb && (cands[i].wpc > 0 ? cands[i].wpc : 0) == dflt.wpc) i_default = i;
+    if (i_default < 0) {
+        i_default = ncand;
+        cands[ncand++] = {dflt.tpb, (int)dflt.cpb, dflt.wpc > 0 ? dflt.wpc : -1, 1e30};
+    }
 
     const dcs_bf_tuning saved = c->tune;
     c->tuning_now = true;
+    auto use = [&](const cand &k) {
+        c->tune.form = 1;
+        c->tune.tiles_per_block = k.tpb;
+        c->tune.chan_per_block = k.cpb;
+        c->tune.wg_per_cu = k.wpc;
+        c->tune.nontemporal = 1;
+    };
     hipEvent_t e0 = nullptr, e1 = nullptr;
     int st = (int)hipEventCreate(&e0);
     if (st == 0) st = (int)hipEventCreate(&e1);
@@ -901,60 +986,33 @@ int dcs_bf_autotune(dcs_bf_context *c, int bitwidth, void *d_out, size_t out_byt
         for (int i = 0; i < ncand && st == 0; i++) {
             // second round: only candidates within 4 % of the first round's best (the device also
             // slows by ~1 % over the first seconds of sustained load, so a short tuner is a better one)
-            if (rnd == 1 && cands[i].best_ms > 1.04 * best_so_far) continue;
-            c->tune.form = 1;
-            c->tune.tiles_per_block = cands[i].tpb;
-            c->tune.chan_per_block = cands[i].cpb;
-            c->tune.wg_per_cu = cands[i].wpc;
-            c->tune.nontemporal = 1;
+            if (rnd == 1 && i != i_default && cands[i].best_ms > 1.04 * best_so_far) continue;
+            use(cands[i]);
             for (int k = 0; k < n_settle && st == 0; k++) st = dcs_bf_generate_slab(c, bitwidth, 1, 1, 0, nc, d_out, out_bytes, stream);
             float ms = 0.0f;
             if (st == 0) st = time_launches(n_timed, &ms);
             if (st == 0 && ms / n_timed < cands[i].best_ms) cands[i].best_ms = ms / n_timed;
         }
     }
-    // Play-off: the short trials rank neighbours within their noise (2-3 %), so the four best
-    // run again, longer (settle, then ~12 ms timed, two interleaved rounds); the mean decides.
+    // Play-off: the short trials rank neighbours within their noise (2-3 %), so the four best and
+    // the library default run again, longer (settle, then ~12 ms timed, three interleaved rounds;
+    // the mean decides).  A challenger replaces the default only if it is more than 0.7 % faster:
+    // below that the ranking is noise, and the default is the geometry the profiles describe.
     int order[32];
     for (int i = 0; i < ncand; i++) order[i] = i;
     for (int i = 0; i < ncand; i++) // selection sort, ncand <= 32
         for (int j = i + 1; j < ncand; j++)
             if (cands[order[j]].best_ms < cands[order[i]].best_ms) { const int t = order[i]; order[i] = order[j]; order[j] = t; }
-    int nfinal = ncand < 4 ? ncand : 4;
-    // the library default always takes part, so that the tuner cannot end below it by mis-ranking a short trial
-    {
-        int tpb_d;
-        uint32_t cpb_d;
-        bool nt_d;
-        dcs_bf_tuning none;
-        std::memset(&none, 0, sizeof(none));
-        const dcs_bf_tuning keep = c->tune;
-        c->tune = none;
-        c->tune.nontemporal = -1;
-        pick_geometry(c, out16, nc, 1, &tpb_d, &cpb_d, &nt_d);
-        const int wpc_d = pick_wg_per_cu(c, out16);
-        c->tune = keep;
-        int pos = -1;
-        for (int i = 0; i < ncand; i++)
-            if (cands[order[i]].tpb == tpb_d && cands[order[i]].cpb == (int)cpb_d &&
-                (cands[order[i]].wpc > 0 ? cands[order[i]].wpc : 0) == wpc_d)
-                pos = i;
-        if (pos >= nfinal && nfinal < 5) { // move it to the end of the finalists
-            const int t = order[pos];
-            for (int i = pos; i > nfinal; i--) order[i] = order[i - 1];
-            order[nfinal++] = t;
-        }
-    }
+    int finalists[5];
+    int nfinal = 0;
+    for (int i = 0; i < ncand && nfinal < 4; i++)
+        if (order[i] != i_default) finalists[nfinal++] = order[i];
+    finalists[nfinal++] = i_default;
     double final_ms[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
     const int n_final = (int)std::fmin(800.0, std::fmax(8.0, std::ceil(12.0 / one)));
-    for (int rnd = 0; rnd < 2 && st == 0; rnd++) {
+    for (int rnd = 0; rnd < 3 && st == 0; rnd++) {
         for (int f = 0; f < nfinal && st == 0; f++) {
-            const cand &k = cands[order[f]];
-            c->tune.form = 1;
-            c->tune.tiles_per_block = k.tpb;
-            c->tune.chan_per_block = k.cpb;
-            c->tune.wg_per_cu = k.wpc;
-            c->tune.nontemporal = 1;
+            use(cands[finalists[f]]);
             for (int i = 0; i < n_settle && st == 0; i++) st = dcs_bf_generate_slab(c, bitwidth, 1, 1, 0, nc, d_out, out_bytes, stream);
             float ms = 0.0f;
             if (st == 0) st = time_launches(n_final, &ms);
@@ -963,24 +1021,23 @@ int dcs_bf_autotune(dcs_bf_context *c, int bitwidth, void *d_out, size_t out_byt
     }
     if (e0) (void)hipEventDestroy(e0);
     if (e1) (void)hipEventDestroy(e1);
-    c->tune = saved;
-    if (st != 0) {
-        c->tuning_now = false;
-        return st;
+    int best = i_default;
+    double best_ms = final_ms[nfinal - 1] / 1.007; // what a challenger has to beat
+    for (int f = 0; f + 1 < nfinal && st == 0; f++)
+        if (final_ms[f] < best_ms) { best_ms = final_ms[f]; best = finalists[f]; }
+    if (st == 0) {
+        // leave the device settled on the chosen geometry (still under the tuner's kernel symbols)
+        use(cands[best]);
+        for (int k = 0; k < n_settle && st == 0; k++) st = dcs_bf_generate_slab(c, bitwidth, 1, 1, 0, nc, d_out, out_bytes, stream);
     }
-    int best = order[0];
-    for (int f = 1; f < nfinal; f++)
-        if (final_ms[f] < final_ms[0]) { final_ms[0] = final_ms[f]; best = order[f]; }
-    c->tune.form = 1;
-    c->tune.tiles_per_block = cands[best].tpb;
-    c->tune.chan_per_block = cands[best].cpb;
-    c->tune.wg_per_cu = cands[best].wpc;
-    c->tune.nontemporal = 1;
-    // leave the device settled on the chosen geometry (still under the tuner's kernel symbols)
-    for (int k = 0; k < n_settle && st == 0; k++) st = dcs_bf_generate_slab(c, bitwidth, 1, 1, 0, nc, d_out, out_bytes, stream);
+    c->tune = saved;
     c->tuning_now = false;
     if (st != 0) return st;
-    if (chosen) *chosen = c->tune;
+    slot.valid = true;
+    slot.tpb = cands[best].tpb;
+    slot.cpb = cands[best].cpb;
+    slot.wpc = cands[best].wpc;
+    report();
     return DCS_OK;
 }
 

@@ -220,14 +220,18 @@ int dcs_bf_generate_and_beamform(dcs_bf_context *ctx, uint64_t t0, uint32_t nt, 
 int dcs_bf_generate_and_beamform_dt(dcs_bf_context *ctx, const float *dt, uint32_t nt, const int8_t *d_antenna,
                                     size_t antenna_bytes, float *d_beams, size_t beams_bytes, void *stream);
 
-/* Launch-geometry knobs (all 0 / NULL = library defaults; DESIGN.md "launch
- * geometry").  Two forms of the MULTIPLE_CHANNELS_AND_TIMESTAMPS generator
- * exist and give identical bits:
+/* Launch-geometry knobs (all 0 / NULL = the library's shape-aware defaults, DESIGN.md "launch
+ * geometry": per launch the library looks at the tiles per row, the workgroups the launch makes and
+ * its bytes -- fp32: 1 tile x 12 channels per workgroup and at most 6 workgroups per CU when there is
+ * plenty of work, 10 channels without limit for rows of >= 2048 tiles, 2 tiles x 16 channels for
+ * launch-bound tensors of <= 32 MiB; fp16: 128 channels, fewer while the chip would be left under 2048
+ * workgroups; no residency limit when every workgroup is resident at once).  Two forms of the
+ * MULTIPLE_CHANNELS_AND_TIMESTAMPS generator exist and give identical bits:
  *   form 1 "tiled": a workgroup keeps its pairs' terms in registers and walks
  *           chan_per_block channels (tiles_per_block 1-KiB tiles wide);
  *   form 2 "rows":  a small terms table is written first, then short waves
  *           (waves_per_block adjacent 1-KiB tiles x rows_per_wave channel rows)
- *           stream the tensor in address order -- the form HBM sustains best.
+ *           stream the tensor in address order.
  * MULTIPLE_CHANNELS always uses form 1 (the reference's per-time-step shape). */
 struct dcs_bf_tuning {
     int32_t form;            /* 0 default, 1 tiled, 2 rows */
@@ -244,21 +248,24 @@ struct dcs_bf_tuning {
     int32_t math_mode;       /* A/B of the arithmetic forms (all give the same bits): bit 0 = keep the 5-op
                               * divide even where the 3-op form was verified exact for this divisor; bit 1 =
                               * keep the full-degree polynomials even where the low-degree ones are proven */
-    int32_t wg_per_cu;       /* form 1: 0 = default (fp32: 6), -1 = no limit, 2..7 = at most this many workgroups resident per CU (the launch
+    int32_t wg_per_cu;       /* form 1: 0 = default (fp32: 6 for launches that oversubscribe the chip), -1 = no limit, 2..7 = at most this many workgroups resident per CU (the launch
                               * asks for unused dynamic LDS to that end): fewer waves in flight keep the store stream
                               * closer to address order (profiles/r01_store_patterns.md, "Fewer workgroups in flight") */
 };
 int dcs_bf_set_tuning(dcs_bf_context *ctx, const struct dcs_bf_tuning *t);
 
-/* Measure the tiled form's launch geometries on THIS device for THIS shape (and the
- * delay table currently set) and keep the fastest: the optimum is sharp and moves with
- * shape and arithmetic form (profiles/r01_geometry_sweep.md).  Generates channels
- * [0, min(nr_channels, out_bytes / row)) of time index 1 into d_out repeatedly
- * (25 trial geometries x 2 rounds; each trial first settles ~20 ms on its own geometry, because the
- * first launches after a change of access pattern run slower, then times ~3 ms: < 1 s in all);
- * blocks on events, so it cannot be captured in a graph.  The chosen
- * knobs are written to *chosen (may be NULL) and stay in effect for this context.
- * Results do not depend on the geometry (every one gives the same bits). */
+/* Measure the tiled form's launch geometries on THIS device for THIS shape (and the delay table
+ * currently set) and keep the fastest for large launches of this output width: the optimum is sharp
+ * and moves with shape and arithmetic form (profiles/r01_geometry_sweep.md, profiles/r02_autotune.md).
+ * Generates channels [0, min(nr_channels, out_bytes / row)) of time index 1 into d_out repeatedly
+ * (~25 trial geometries x 2 rounds; each trial first settles ~20 ms on its own geometry, because the
+ * first launches after a change of access pattern run slower, then times ~3 ms; the four best meet the
+ * library's shape-aware default in a play-off, and a challenger replaces the default only when it is
+ * more than 0.7 % faster: ~1 s in all); blocks on events, so it cannot be captured in a graph.  The
+ * result is CACHED in the context per output width -- a second call returns it at once;
+ * dcs_bf_set_tuning(ctx, NULL) forgets it -- and *chosen (may be NULL) reports it.  Knobs set
+ * explicitly with dcs_bf_set_tuning keep precedence over it.  Results do not depend on the geometry
+ * (every one gives the same bits). */
 int dcs_bf_autotune(dcs_bf_context *ctx, int bitwidth, void *d_out, size_t out_bytes, void *stream,
                     struct dcs_bf_tuning *chosen);
 

@@ -689,8 +689,15 @@ def test_autotune_keeps_results(gpu, oracle):
         g.upload_delays(table)
         nbytes = g.output_bytes(bw, 2)
         buf = gpu.mem_alloc(nbytes)
+        import time
+
+        t0 = time.perf_counter()
         chosen = g.autotune(buf, nbytes, bitwidth=bw)
+        t_first = time.perf_counter() - t0
         assert chosen["form"] == 1 and chosen["tiles_per_block"] in (1, 2, 4) and chosen["chan_per_block"] >= 1
+        t0 = time.perf_counter()
+        again = g.autotune(buf, nbytes, bitwidth=bw)  # cached in the context per output width
+        assert again == chosen and time.perf_counter() - t0 < 0.25 * t_first
         g.generate(buf, nbytes, t0=5, nt=2, bitwidth=bw)
         exp = oracle.generate(op, table, 5, 2)
         if bw == 1:
@@ -989,7 +996,7 @@ def test_generate_dt_off_grid_times(gpu, oracle, kernel):
     g.generate_slab_dt(buf, nbs, c0, nc, dts)
     gs = np.empty((dts.size, nc, bp.NR_STATIONS, bp.NR_BEAMS, 2), dtype=np.float32)
     gpu.memcpy_dtoh(gs, buf)
-    assert np.array_equal(gs.view(np.uint32), np.ascontiguousarray(got[:, c0:c0 + nc]).view(np.uint32))
+    _check(oracle, gs, np.ascontiguousarray(exp[:, c0:c0 + nc]))  # (NAIVE picks its polynomial degree per pair, the tiled form per wave: not bit-equal)
     g.close()
 
 

@@ -49,6 +49,9 @@ SHAPES = {  # name: (ant, beams, chan, nt)
     "narrow": (16, 16, 32768, 1),
     "wide": (64, 4096, 2048, 1),
     "small": (16, 64, 2048, 1),
+    "small2": (64, 16, 512, 1),
+    "small3": (16, 64, 4096, 1),
+    "wide2": (256, 1024, 1024, 1),
 }
 
 
@@ -138,20 +141,34 @@ def cmd_geometry(args):
 
 def cmd_refshape(args):
     """The tensor runBeamformerTests times (BeamformerParameters.h defaults): a3 in one launch, a1 / a2 as
-    256 launches from the host loop (BeamformerCoefficientTest.cu:230-250)."""
+    256 launches from the host loop (BeamformerCoefficientTest.cu:230-250); --sweep: a2 / a3 per geometry."""
     bp = BeamformerParameters()
     g = SteeringCoefficientGenerator(bp)
     g.upload_delays(simulate_input(bp))
     nt = 256
     nb = g.output_bytes(1, nt)
     buf = device.mem_alloc(nb)
+
+    def t(kern, bw):
+        nbb = g.output_bytes(bw, nt)
+        return nbb, min(per_launch_ms(lambda: g.generate(buf, nbb, t0=0, nt=nt, kernel=kern, bitwidth=bw), settle_ms=20, timed_ms=40)
+                        for _ in range(3))
+
     for kern, name in ((2, "MULTIPLE_CHANNELS_AND_TIMESTAMPS (1 launch)"), (1, "MULTIPLE_CHANNELS (256 launches)"), (0, "NAIVE (256 launches)")):
         for bw in ((1, 0) if kern else (1,)):
-            nbb = g.output_bytes(bw, nt)
-            ms = min(per_launch_ms(lambda: g.generate(buf, nbb, t0=0, nt=nt, kernel=kern, bitwidth=bw), settle_ms=20, timed_ms=40)
-                     for _ in range(3))
+            nbb, ms = t(kern, bw)
             print(f"{name} b{32 if bw else 16}: {ms * 1e3:.1f} us per tensor = {ms * 1e3 / (nt if kern != 2 else 1):.2f} us per launch, "
                   f"{nbb / ms / 1e9:.2f} TB/s", flush=True)
+    if args.sweep:
+        for kern in (1, 2):
+            for bw in (1, 0):
+                for tpb in (1, 2, 4):
+                    for cpb in (1, 2, 4, 8, 12, 16, 32, 64):
+                        if cpb * tpb < 4:
+                            continue
+                        g.set_tuning(form=1, tiles_per_block=tpb, chan_per_block=cpb, wg_per_cu=-1)
+                        nbb, ms = t(kern, bw)
+                        print(f"  kernel={kern} b{32 if bw else 16} tpb={tpb} cpb={cpb:2d}: {ms * 1e3 / (nt if kern != 2 else 1):.2f} us per launch", flush=True)
     g.close()
 
 
@@ -336,7 +353,8 @@ def main():
     p.add_argument("--bits", type=int, default=32, choices=[16, 32])
     p.add_argument("--sweep", action="store_true")
     p.add_argument("--verbose", action="store_true")
-    sub.add_parser("refshape")
+    p = sub.add_parser("refshape")
+    p.add_argument("--sweep", action="store_true")
     p = sub.add_parser("fp16")
     p.add_argument("--modes", default="0,4")
     p.add_argument("--cpb", default="64,128,256")
