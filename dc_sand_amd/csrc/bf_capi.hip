@@ -65,7 +65,7 @@ dcs_bf_consts make_consts(const dcs_bf_params *p)
     if (!(k.fRotBoundScale >= 0.0f)) k.fRotBoundScale = INFINITY;
     k.uDiv3Exact = 0u; // set by verify_div3() once a device is at hand
     k.fLowDegLimit = 500.0f;
-    k.fPad = 0.0f;
+    k.uHalfMath = 0u;
     k.dHalfChannels = p->nr_channels / 2.0; // BeamformerCoefficientTest.cu:323
     k.dDenominator = (double)D;
     return k;
@@ -424,6 +424,7 @@ int dcs_bf_set_tuning(dcs_bf_context *c, const dcs_bf_tuning *t)
         c->tune.rows_same_tile = -1;
         c->k.uDiv3Exact = c->div3_verified;
         c->k.fLowDegLimit = 500.0f;
+        c->k.uHalfMath = 0u;
         c->tuned[0].valid = c->tuned[1].valid = false; // forget what dcs_bf_autotune measured, too
         return DCS_OK;
     }
@@ -437,7 +438,7 @@ int dcs_bf_set_tuning(dcs_bf_context *c, const dcs_bf_tuning *t)
     if (t->rows_per_wave < 0 || t->rows_per_wave > 4) return DCS_ERR_INVALID_ARGUMENT;
     if (t->rows_same_tile < -1 || t->rows_same_tile > 1) return DCS_ERR_INVALID_ARGUMENT;
     if (t->xcd_remap < -1 || t->xcd_remap > 1) return DCS_ERR_INVALID_ARGUMENT;
-    if (t->math_mode < 0 || t->math_mode > 3) return DCS_ERR_INVALID_ARGUMENT;
+    if (t->math_mode < 0 || t->math_mode > 7) return DCS_ERR_INVALID_ARGUMENT;
 #ifdef DCS_PROBES
     if (t->probe_pace < 0 || t->probe_pace > 4096) return DCS_ERR_INVALID_ARGUMENT;
 #else
@@ -449,6 +450,8 @@ int dcs_bf_set_tuning(dcs_bf_context *c, const dcs_bf_tuning *t)
     // math_mode bit 0: keep the 5-op divide; bit 1: keep the full polynomials
     c->k.uDiv3Exact = (t->math_mode & 1) ? 0u : c->div3_verified;
     c->k.fLowDegLimit = (t->math_mode & 2) ? 0.0f : 500.0f;
+    // bit 2: b16 output uses the binary16-sized sincos (tiled form, waves outside the slow class)
+    c->k.uHalfMath = (t->math_mode & 4) ? 1u : 0u;
     return DCS_OK;
 }
 
@@ -541,7 +544,6 @@ int prepare_tiled(dcs_bf_context *c, bool out16, const float *dt_dev, float dt0,
 {
     bf_tiled_args a;
     std::memset(&a, 0, sizeof(a));
-    if (dt_host && nt <= kDtInline) std::memcpy(a.dt_inline, dt_host, (size_t)nt * sizeof(float));
     a.delays = c->d_table[c->cur];
     a.out = d_out;
     a.dt_dev = dt_dev;
@@ -559,7 +561,7 @@ int prepare_tiled(dcs_bf_context *c, bool out16, const float *dt_dev, float dt0,
 #ifdef DCS_PROBES
     a.pace = (uint32_t)c->tune.probe_pace;
 #endif
-    const int st = (int)bf_prepare_tiled(a, out16, tpb | (c->tune.probe_nomath ? 0x100 : 0) | (c->tuning_now ? 0x200 : 0), ntstore, l);
+    const int st = (int)bf_prepare_tiled(a, dt_host, out16, tpb | (c->tune.probe_nomath ? 0x100 : 0) | (c->tuning_now ? 0x200 : 0), ntstore, l);
     if (st == DCS_OK && g.wpc > 0) l->shared = lds_pad_for(g.wpc, out16, tpb);
     return st;
 }
@@ -1123,8 +1125,8 @@ int dcs_bf_stream_tick_dt(dcs_bf_stream *s, float dt, const dcs_delay_vals *new_
         s->table_pending = true;
         c->cur = nxt;
     }
-    s->launch.args.dt0 = dt;
-    s->launch.args.delays = c->d_table[c->cur];
+    s->launch.args.a.dt0 = dt;
+    s->launch.args.a.delays = c->d_table[c->cur];
     void *params[] = {&s->launch.args};
     hipKernelNodeParams np;
     std::memset(&np, 0, sizeof(np));

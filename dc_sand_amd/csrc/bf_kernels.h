@@ -14,7 +14,7 @@ struct bf_tiled_args {
     const dcs_delay_vals *delays; // compact table [n_pairs]
     void *out;                    // [nt][nc][n_pairs] of {re,im} (fp32 pair or half2)
     const float *dt_dev;          // fDeltaTime per time step (device), or nullptr
-    float dt0;                    // used when dt_dev == nullptr (nt must be 1)
+    float dt0;                    // used when dt_dev == nullptr and nt == 1
     uint32_t n_pairs;
     uint32_t c0, nc;              // channel slab
     uint32_t nt;
@@ -26,12 +26,17 @@ struct bf_tiled_args {
     uint32_t pace;                // probes build only: 64-cycle sleeps before each store of the fast loop
 #endif
     dcs_bf_consts k;
-    // fDeltaTime of up to kDtInline time steps by value (kernel arguments): the reference's default
-    // tensor (256 time steps, 134 MB) is a 22 us kernel, and a pinned->device copy of the dt table in
-    // front of it cost another 9 us.  Used when dt_dev == nullptr and nt > 1; [0] == dt0.
-    float dt_inline[256];
 };
+// The same with fDeltaTime of up to kDtInline time steps by value (kernel arguments): the reference's
+// default tensor (256 time steps, 134 MB) is a 22 us kernel, and a pinned->device copy of the dt table
+// in front of it cost another 9 us.  Used when a.dt_dev == nullptr and a.nt > 1; dt_inline[0] == a.dt0.
+// One-time-step launches (the per-time-step host loops of NAIVE / MULTIPLE_CHANNELS, every streaming
+// tick) take the 0.1 KiB bf_tiled_args alone: those loops are bound by the host's launch rate.
 constexpr uint32_t kDtInline = 256;
+struct bf_tiled_args_inl {
+    bf_tiled_args a;
+    float dt_inline[kDtInline];
+};
 
 // A resolved launch (kernel instantiation, geometry, final arguments): what
 // bf_launch_tiled enqueues, and what a hipGraph kernel node is built from.
@@ -39,14 +44,11 @@ struct bf_kernel_launch {
     const void *func; // nullptr: nothing to launch (empty shape)
     dim3 grid, block;
     uint32_t shared; // dynamic LDS bytes requested (occupancy limiter; the kernel does not use them)
-    bf_tiled_args args;
+    bf_tiled_args_inl args; // the kernel's parameter is `args` (inline form) or `args.a` (same address)
 };
-hipError_t bf_prepare_tiled(const bf_tiled_args &a, bool out16, int tiles_per_block, bool nontemporal,
-                            bf_kernel_launch *out);
-
-// tiles_per_block in {1,2,4}; out16: packed half2 output; nontemporal: nt stores.
-hipError_t bf_launch_tiled(const bf_tiled_args &a, bool out16, int tiles_per_block,
-                           bool nontemporal, hipStream_t stream);
+// dt_inline: nullptr, or a.nt values (a.nt <= kDtInline) that travel in the kernel arguments
+hipError_t bf_prepare_tiled(const bf_tiled_args &a, const float *dt_inline, bool out16, int tiles_per_block,
+                            bool nontemporal, bf_kernel_launch *out);
 
 // Row-streaming form: a terms table written by bf_launch_terms, then one short
 // wave per (1-KiB tile, rows_per_wave channel rows).

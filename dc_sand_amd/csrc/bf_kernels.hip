@@ -27,6 +27,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cstring>
 #include <type_traits>
 
 namespace {
@@ -116,9 +117,16 @@ __device__ __forceinline__ uint32_t pack_half2(const float re, const float im)
 //             dcs_bf_autotune, so that a profiler's per-kernel statistics of the
 //             production launches are not mixed with the tuner's trial geometries
 // ---------------------------------------------------------------------------
-template <bool OUT16, int TPB, bool NT, bool ALIGNED, bool NOMATH, int TAG = 0>
-__global__ void __launch_bounds__(kBlock) bf_tiled_kernel(const bf_tiled_args a)
+//   INL     : the kernel parameter is bf_tiled_args_inl (fDeltaTime of up to 256 time steps by value)
+template <bool OUT16, int TPB, bool NT, bool ALIGNED, bool NOMATH, int TAG = 0, bool INL = false>
+__global__ void __launch_bounds__(kBlock) bf_tiled_kernel(const std::conditional_t<INL, bf_tiled_args_inl, bf_tiled_args> args)
 {
+    const bf_tiled_args &a = [&]() -> const bf_tiled_args & {
+        if constexpr (INL)
+            return args.a;
+        else
+            return args;
+    }();
     constexpr int PPL = OUT16 ? 4 : 2;
     constexpr int TILE = 64 * PPL;
     constexpr int ROWS = 4 / TPB;
@@ -136,7 +144,11 @@ __global__ void __launch_bounds__(kBlock) bf_tiled_kernel(const bf_tiled_args a)
     const uint32_t cb = rest % a.n_cblocks;
     const uint32_t t = rest / a.n_cblocks;
 
-    const float dt = a.dt_dev ? a.dt_dev[t] : (a.nt > 1 ? a.dt_inline[t] : a.dt0);
+    float dt;
+    if constexpr (INL)
+        dt = a.dt_dev ? a.dt_dev[t] : args.dt_inline[t];
+    else
+        dt = a.dt_dev ? a.dt_dev[t] : a.dt0;
     const uint32_t pair_base = tg * (uint32_t)(TPB * TILE);
 
     // ---- stage the channel-independent terms of this workgroup's pairs in LDS
@@ -227,7 +239,36 @@ __global__ void __launch_bounds__(kBlock) bf_tiled_kernel(const bf_tiled_args a)
         return;
     }
 
-    if (!wave_slow) {
+    bool half_math = false;
+    if constexpr (OUT16) half_math = a.k.uHalfMath != 0u && !wave_slow;
+    if (half_math) {
+        if constexpr (OUT16) {
+            // b16 output, no pair of the wave in the slow class (every |fRotation| < 32000), opted in (math_mode
+            // bit 2): the binary16-sized sincos (bf_math.h: dcs_sincos_half2), which yields the packed (re, im) word
+            auto walk = [&](auto div3) {
+#pragma unroll 2
+                for (uint32_t c = cbeg + row; c < cend; c += ROWS) {
+                    const float fChan = (float)(a.c0 + c);
+                    uint32_t w[PPL];
+#pragma unroll
+                    for (int j = 0; j < PPL; j++)
+                        w[j] = dcs_sincos_half2(dcs_rotation<decltype(div3)::value>(fRate[j], fPhase0[j], fChan, D, y));
+                    if constexpr (ALIGNED) {
+                        store_global<NT>(reinterpret_cast<uintx4 *>(dst), uintx4{w[0], w[1], w[2], w[3]});
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < PPL; j++)
+                            if (p0 + j < a.n_pairs) store_global<NT>(reinterpret_cast<uint32_t *>(dst) + j, w[j]);
+                    }
+                    dst += step;
+                }
+            };
+            if (a.k.uDiv3Exact != 0u)
+                walk(std::true_type{});
+            else
+                walk(std::false_type{});
+        }
+    } else if (!wave_slow) {
         dispatch_fast(a.k.uDiv3Exact != 0u, wave_low, [&](auto div3, auto lowdeg) {
 #pragma unroll 2
             for (uint32_t c = cbeg + row; c < cend; c += ROWS) {
@@ -627,8 +668,9 @@ __global__ void __launch_bounds__(kBlock) bf_gather_beams_kernel(dcs_delay_vals 
 }
 
 template <bool OUT16, int TPB, bool NT, bool ALIGNED>
-const void *tiled_fn_nm(bool nomath, bool tuner)
+const void *tiled_fn_nm(bool nomath, bool tuner, bool inl)
 {
+    if (inl) return (nomath || tuner) ? nullptr : reinterpret_cast<const void *>(&bf_tiled_kernel<OUT16, TPB, NT, ALIGNED, false, 0, true>);
     if (tuner) return reinterpret_cast<const void *>(&bf_tiled_kernel<OUT16, TPB, NT, ALIGNED, false, 1>);
 #ifdef DCS_PROBES
     if (nomath) return reinterpret_cast<const void *>(&bf_tiled_kernel<OUT16, TPB, NT, ALIGNED, true>);
@@ -639,29 +681,30 @@ const void *tiled_fn_nm(bool nomath, bool tuner)
 }
 
 template <bool OUT16, int TPB>
-const void *tiled_fn_t(bool nt, bool aligned, bool nomath, bool tuner)
+const void *tiled_fn_t(bool nt, bool aligned, bool nomath, bool tuner, bool inl)
 {
-    if (nt) return aligned ? tiled_fn_nm<OUT16, TPB, true, true>(nomath, tuner) : tiled_fn_nm<OUT16, TPB, true, false>(nomath, tuner);
-    return aligned ? tiled_fn_nm<OUT16, TPB, false, true>(nomath, tuner) : tiled_fn_nm<OUT16, TPB, false, false>(nomath, tuner);
+    if (nt) return aligned ? tiled_fn_nm<OUT16, TPB, true, true>(nomath, tuner, inl) : tiled_fn_nm<OUT16, TPB, true, false>(nomath, tuner, inl);
+    return aligned ? tiled_fn_nm<OUT16, TPB, false, true>(nomath, tuner, inl) : tiled_fn_nm<OUT16, TPB, false, false>(nomath, tuner, inl);
 }
 
 template <bool OUT16>
-const void *tiled_fn_o(int tpb, bool nt, bool aligned, bool nomath, bool tuner)
+const void *tiled_fn_o(int tpb, bool nt, bool aligned, bool nomath, bool tuner, bool inl)
 {
     switch (tpb) {
-    case 1: return tiled_fn_t<OUT16, 1>(nt, aligned, nomath, tuner);
-    case 2: return tiled_fn_t<OUT16, 2>(nt, aligned, nomath, tuner);
-    case 4: return tiled_fn_t<OUT16, 4>(nt, aligned, nomath, tuner);
+    case 1: return tiled_fn_t<OUT16, 1>(nt, aligned, nomath, tuner, inl);
+    case 2: return tiled_fn_t<OUT16, 2>(nt, aligned, nomath, tuner, inl);
+    case 4: return tiled_fn_t<OUT16, 4>(nt, aligned, nomath, tuner, inl);
     default: return nullptr;
     }
 }
 
 } // namespace
 
-hipError_t bf_prepare_tiled(const bf_tiled_args &a_in, bool out16, int tiles_per_block, bool nontemporal,
-                            bf_kernel_launch *out)
+hipError_t bf_prepare_tiled(const bf_tiled_args &a_in, const float *dt_inline, bool out16, int tiles_per_block,
+                            bool nontemporal, bf_kernel_launch *out)
 {
-    bf_tiled_args a = a_in;
+    bf_tiled_args &a = out->args.a;
+    a = a_in;
     out->func = nullptr;
     if (a.n_pairs == 0 || a.nc == 0 || a.nt == 0) return hipSuccess; // nothing to launch
     if (a.chan_per_block == 0) return hipErrorInvalidValue;
@@ -674,28 +717,19 @@ hipError_t bf_prepare_tiled(const bf_tiled_args &a_in, bool out16, int tiles_per
     a.n_cblocks = (a.nc + a.chan_per_block - 1) / a.chan_per_block;
     const uint64_t blocks = (uint64_t)a.n_tile_groups * a.n_cblocks * a.nt;
     if (blocks == 0 || blocks > 0x7fffffffull) return hipErrorInvalidValue;
-    if (a.dt_dev == nullptr && a.nt > kDtInline) return hipErrorInvalidValue;
+    const bool inl = a.dt_dev == nullptr && a.nt > 1;
+    if (inl && (dt_inline == nullptr || a.nt > kDtInline)) return hipErrorInvalidValue;
+    if (inl) std::memcpy(out->args.dt_inline, dt_inline, (size_t)a.nt * sizeof(float));
     if (blocks % 8u) a.xcd_remap = 0; // the renumbering is a bijection only then
     const bool aligned = (a.n_pairs % ppl) == 0 && (reinterpret_cast<uintptr_t>(a.out) % 16u) == 0;
-    const void *fn = out16 ? tiled_fn_o<true>(tiles_per_block, nontemporal, aligned, nomath, tuner)
-                           : tiled_fn_o<false>(tiles_per_block, nontemporal, aligned, nomath, tuner);
+    const void *fn = out16 ? tiled_fn_o<true>(tiles_per_block, nontemporal, aligned, nomath, tuner, inl)
+                           : tiled_fn_o<false>(tiles_per_block, nontemporal, aligned, nomath, tuner, inl);
     if (!fn) return hipErrorInvalidValue;
     out->func = fn;
     out->grid = dim3((uint32_t)blocks);
     out->block = dim3(kBlock);
     out->shared = 0;
-    out->args = a;
     return hipSuccess;
-}
-
-hipError_t bf_launch_tiled(const bf_tiled_args &a, bool out16, int tiles_per_block, bool nontemporal,
-                           hipStream_t stream)
-{
-    bf_kernel_launch l;
-    hipError_t e = bf_prepare_tiled(a, out16, tiles_per_block, nontemporal, &l);
-    if (e != hipSuccess || l.func == nullptr) return e;
-    void *params[] = {&l.args};
-    return hipLaunchKernel(l.func, l.grid, l.block, params, l.shared, stream);
 }
 
 hipError_t bf_launch_naive(const bf_naive_args &a, hipStream_t stream)

@@ -45,7 +45,7 @@ struct dcs_bf_consts {
     float fRotBoundScale;    // >= pi * (NR_CHANNELS-1) / fDenominator, with margin
     uint32_t uDiv3Exact;     // 1: dcs_div_const3 verified == IEEE divide for THIS fDenominator (bf_capi.hip)
     float fLowDegLimit;      // 500: |fRotation| bound below which the low-degree polynomials are used (0 = never)
-    float fPad;
+    uint32_t uHalfMath;      // 1: b16 output uses dcs_sincos_half2 (binary16-sized sincos) for every wave outside the slow class
     double dHalfChannels;    // NR_CHANNELS / 2.0 (.cu:323)
     double dDenominator;     // (double) fDenominator (.cu:323)
 };
@@ -254,6 +254,92 @@ DCS_HD void dcs_sincos_fast(const float x, float *fSin, float *fCos)
     const uint32_t uc = dcs_f32_bits(swap ? -sr : cr);     // one v_cndmask with a neg modifier (sign flip == xor t31)
     *fSin = dcs_bits_f32(dcs_xor_sign_of(us, t30));
     *fCos = dcs_bits_f32(dcs_xor_sign_of(uc, t30));
+}
+
+// ---------------------------------------------------------------------------
+// sin and cos of |x| < 32768 for a BINARY16 result, packed as the b16 output wants it:
+// low half = cos (re), high half = sin (im) (reference: __floats2half2_rn(re, im),
+// BeamformerKernels.cu:113,182).  Opt-in (dcs_bf_tuning::math_mode bit 2); the default b16
+// path rounds the 1-ULP fp32 pair instead.
+//
+// Sized for an 11-bit significand: two-term Cody-Waite reduction (the dropped third term is
+// < 4e-11 for |n| <= 20861), sin to r^5 and cos to r^4 in fp32 (minimax on [-pi/4, pi/4]:
+// relative error 1.9e-6 / 1.5e-5, i.e. < 0.004 / 0.03 of a binary16 ulp), ONE conversion of the
+// pair (v_cvt_pk_f16_f32, round to nearest even), then the quadrant on the packed word:
+// halves rotated by 16 * (n mod 2) with v_alignbit_b32, sign of sin = bit 1 of n, sign of
+// cos = bit 1 of n + 1, two v_bitop3_b32.  23 VALU operations per coefficient with the
+// rotation's 6, against 28-30 for the fp32-then-round form.
+// tests/test_numerics.py sweeps EVERY fp32 argument below 32768: each half is within one
+// binary16 ulp of RN16 of the correctly rounded value (it IS that value for 99.8 % of them,
+// 99.1 % in [1, 512)), and the count that differs from RN16(fp32 path) is reported.
+// ---------------------------------------------------------------------------
+#define DCS_HS1 -1.66633813956683030e-01f
+#define DCS_HS2 8.16309870382948000e-03f
+#define DCS_HC0 -4.99760307529649600e-01f
+#define DCS_HC1 4.04579233108025100e-02f
+
+// IEEE binary16 round-to-nearest-even of an fp32 (what v_cvt_pk_f16_f32 does per element in the
+// default rounding mode).  The host form is bit arithmetic; the device form is the instruction.
+DCS_HD uint32_t dcs_f32_to_f16_bits(const float x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    const _Float16 h = (_Float16)x;
+    return (uint32_t)__builtin_bit_cast(unsigned short, h);
+#else
+    const uint32_t u = dcs_f32_bits(x), sign = (u >> 16) & 0x8000u, a = u & 0x7fffffffu;
+    if (a >= 0x7f800000u) return sign | 0x7c00u | (a > 0x7f800000u ? 0x200u | ((a >> 13) & 0x3ffu) : 0u);
+    if (a >= 0x477ff000u) return sign | 0x7c00u;
+    if (a < 0x33000001u) return sign;
+    const int32_t e = (int32_t)(a >> 23) - 127;
+    const uint32_t m = (a & 0x7fffffu) | 0x800000u;
+    const uint32_t shift = e < -14 ? (uint32_t)(-e - 14 + 13) : 13u, hexp = e < -14 ? 0u : (uint32_t)(e + 15);
+    uint32_t q = m >> shift;
+    const uint32_t rem = m & ((1u << shift) - 1u), half = 1u << (shift - 1);
+    if (rem > half || (rem == half && (q & 1u))) q++;
+    return sign | (hexp == 0 ? q : (((hexp - 1u) << 10) + q));
+#endif
+}
+
+DCS_HD uint32_t dcs_pack_half2(const float lo, const float hi)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef _Float16 dcs_halfx2 __attribute__((ext_vector_type(2)));
+    dcs_halfx2 h;
+    h.x = (_Float16)lo;
+    h.y = (_Float16)hi;
+    return __builtin_bit_cast(uint32_t, h); // one v_cvt_pk_f16_f32
+#else
+    return dcs_f32_to_f16_bits(lo) | (dcs_f32_to_f16_bits(hi) << 16);
+#endif
+}
+
+// {low half = cos x, high half = sin x}, |x| < 32768 (DCS_SINCOS_FAST_LIMIT).
+DCS_HD uint32_t dcs_sincos_half2(const float x)
+{
+    const float nb = dcs_fmaf(x, DCS_TWO_OVER_PI, DCS_RINT_MAGIC);
+    const float n = nb - DCS_RINT_MAGIC;
+    const uint32_t q = dcs_f32_bits(nb);
+    float r = dcs_fmaf(-n, DCS_PIO2_1, x); // exact
+    r = dcs_fmaf(-n, DCS_PIO2_2, r);
+    const float s = r * r;
+    const float ps = dcs_fmaf(s, DCS_HS2, DCS_HS1);
+    const float pc = dcs_fmaf(s, DCS_HC1, DCS_HC0);
+    const float sr = dcs_fmaf(s * r, ps, r);
+    const float cr = dcs_fmaf(s, pc, 1.0f);
+    const uint32_t p = dcs_pack_half2(cr, sr);
+    // n mod 4:  0: (cr, sr)  1: (-sr, cr)  2: (-cr, -sr)  3: (sr, -cr)   as (cos, sin)
+    const uint32_t amt = q << 4; // bit 4 = n mod 2: rotate the halves by 16 when n is odd
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t sw = __builtin_amdgcn_alignbit(p, p, amt);
+#else
+    const uint32_t sw = (amt & 16u) ? ((p >> 16) | (p << 16)) : p;
+#endif
+    const uint32_t t = dcs_xor_sign_of(sw, q << 30); // sin (high half): sign = bit 1 of n
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_bitop3_b32((q + 1u) << 14, t, 0x8000u, 0x6c); // cos (low half): sign = bit 1 of n + 1
+#else
+    return t ^ (((q + 1u) << 14) & 0x8000u);
+#endif
 }
 
 #endif // DCS_BF_MATH_H

@@ -245,9 +245,18 @@ struct dcs_bf_tuning {
     int32_t rows_same_tile;  /* form 2: -1 default, 0 = the waves take adjacent tiles, 1 = they share one tile and
                               * interleave rows */
     int32_t probe_pace;      /* must be 0 (libdcs_probes.so only: 64-cycle sleeps before each store) */
-    int32_t math_mode;       /* A/B of the arithmetic forms (all give the same bits): bit 0 = keep the 5-op
-                              * divide even where the 3-op form was verified exact for this divisor; bit 1 =
-                              * keep the full-degree polynomials even where the low-degree ones are proven */
+    int32_t math_mode;       /* arithmetic forms.  Bits 0 and 1 are A/B switches that never change a bit of the output:
+                              * bit 0 = keep the 5-op divide even where the 3-op form was verified exact for this
+                              * divisor; bit 1 = keep the full-degree polynomials even where the low-degree ones are
+                              * proven.  Bit 2 (value 4) OPTS IN to the b16 arithmetic form: where the output is b16
+                              * and no pair of a wave needs the slow path (|fRotation| < 32000), sin and cos are evaluated to binary16
+                              * accuracy (two-term reduction, degree 5 / 4) and converted once, instead of rounding the
+                              * 1-ULP fp32 pair: 22 instead of 28 VALU operations per coefficient.  Every half is within
+                              * one binary16 ulp of RN16(correctly rounded value) for EVERY fp32 argument below 32768, and
+                              * equal to it for 99.8 % of them (0.9 % differ in [1, 32768); tests/test_numerics.py, by
+                              * exhaustion).  The reference rounds whatever __sincosf returned and never checks it
+                              * (BeamformerKernels.cu:113-115,182-184; BCT.cu:282-287).  Default off; fp32 output and
+                              * the rows form are unaffected. */
     int32_t wg_per_cu;       /* form 1: 0 = default (fp32: 6 for launches that oversubscribe the chip), -1 = no limit, 2..7 = at most this many workgroups resident per CU (the launch
                               * asks for unused dynamic LDS to that end): fewer waves in flight keep the store stream
                               * closer to address order (profiles/r01_store_patterns.md, "Fewer workgroups in flight") */

@@ -23,7 +23,8 @@ extern "C" {
 
 /* Device evaluation of the two sincos forms on n arguments:
  * which = 0 the library's fast path (full polynomials), 1 __ocml_sincos_f32, 2 the fp64
- * slow path, 3 the fast path with the low-degree polynomials (valid below 512). */
+ * slow path, 3 the fast path with the low-degree polynomials (valid below 512), 4 the b16 arithmetic
+ * form (dcs_sincos_half2: d_sin receives the packed {cos, sin} half2 words, d_cos is not written). */
 int dcs_probe_sincos(int which, const float *d_x, size_t n, float *d_sin, float *d_cos, void *stream);
 /* Pure store kernel with the generator's access pattern and no arithmetic: the
  * measured HBM-write ceiling the roofline fraction is read against. */

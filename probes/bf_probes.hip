@@ -57,6 +57,10 @@ __global__ void __launch_bounds__(kBlock) bf_probe_sincos_kernel(int which, cons
     if (i >= n) return;
     const float v = x[i];
     float fs, fc;
+    if (which == 4) { // the b16 arithmetic form: s[i] receives the packed (cos, sin) half2 word, c[i] is not written
+        reinterpret_cast<uint32_t *>(s)[i] = dcs_sincos_half2(v);
+        return;
+    }
     if (which == 0) {
         dcs_sincos_fast<false>(v, &fs, &fc);
     } else if (which == 3) {
@@ -286,7 +290,7 @@ extern "C" {
 
 int dcs_probe_sincos(int which, const float *d_x, size_t n, float *d_sin, float *d_cos, void *stream)
 {
-    if (which < 0 || which > 3 || (n && (!d_x || !d_sin || !d_cos))) return DCS_ERR_INVALID_ARGUMENT;
+    if (which < 0 || which > 4 || (n && (!d_x || !d_sin || !d_cos))) return DCS_ERR_INVALID_ARGUMENT;
     return (int)bf_launch_probe_sincos(which, d_x, n, d_sin, d_cos, as_stream(stream));
 }
 

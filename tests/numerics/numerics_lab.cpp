@@ -76,6 +76,36 @@ static void *sincos_worker(void *arg)
     return NULL;
 }
 
+static inline int half_ordered(uint32_t h) { return (h & 0x8000u) ? -(int)(h & 0x7fffu) : (int)(h & 0x7fffu); }
+
+/* dcs_sincos_half2 (the b16 arithmetic form) against RN16 of the correctly rounded fp32 value --
+ * the oracle's b16 expectation -- and against RN16 of the fp32 fast path (the default b16 form).
+ * max_a / max_b: max binary16-ulp distance of sin / cos to RN16((float)sin((double)x));
+ * over_a / over_b: arguments beyond 1; unfaithful_a / _b (reused): arguments where it differs at all;
+ * over_f_a / over_f_b (reused): arguments where it differs from RN16(dcs_sincos_fast<true>). */
+static void *half_worker(void *arg)
+{
+    struct sweep_job *j = (struct sweep_job *)arg;
+    for (uint32_t u = j->lo; u < j->hi; u++) {
+        const float x = dcs_bits_f32(u);
+        const uint32_t p = dcs_sincos_half2(x);
+        const uint32_t hc = p & 0xffffu, hs = p >> 16;
+        const uint32_t es = dcs_f32_to_f16_bits((float)sin((double)x)), ec = dcs_f32_to_f16_bits((float)cos((double)x));
+        const uint32_t ds = (uint32_t)abs(half_ordered(hs) - half_ordered(es)), dc = (uint32_t)abs(half_ordered(hc) - half_ordered(ec));
+        if (ds > j->max_a) { j->max_a = ds; j->worst_a = u; }
+        if (dc > j->max_b) { j->max_b = dc; j->worst_b = u; }
+        if (ds > 1) j->over_a++;
+        if (dc > 1) j->over_b++;
+        if (ds) j->unfaithful_a++;
+        if (dc) j->unfaithful_b++;
+        float fs, fc;
+        dcs_sincos_fast<true>(x, &fs, &fc);
+        if (dcs_f32_to_f16_bits(fs) != hs) j->over_f_a++;
+        if (dcs_f32_to_f16_bits(fc) != hc) j->over_f_b++;
+    }
+    return NULL;
+}
+
 static void *div_worker(void *arg)
 {
     struct sweep_job *j = (struct sweep_job *)arg;
@@ -162,6 +192,25 @@ void lab_sincos_sweep_faithful(int lowdeg, uint32_t lo_bits, uint32_t hi_bits, i
     run_sweep(sincos_worker, &p, nthreads, &o);
     res[0] = o.unfaithful_a; res[1] = o.unfaithful_b; res[2] = o.over_f_a; res[3] = o.over_f_b;
     res[4] = o.max_f_a; res[5] = o.max_f_b;
+}
+
+/* The b16 arithmetic form over every fp32 with bit pattern in [lo_bits, hi_bits):
+ * res = {max_half_ulp_sin, max_half_ulp_cos, n_sin_over_1, n_cos_over_1, n_sin_not_rn16_exact, n_cos_not_rn16_exact,
+ *        n_sin_not_rn16_of_fp32_path, n_cos_not_rn16_of_fp32_path, worst_x_bits_sin, worst_x_bits_cos}. */
+void lab_half_sweep(uint32_t lo_bits, uint32_t hi_bits, int nthreads, uint64_t *res)
+{
+    struct sweep_job p = {}, o;
+    p.lo = lo_bits;
+    p.hi = hi_bits;
+    run_sweep(half_worker, &p, nthreads, &o);
+    res[0] = o.max_a; res[1] = o.max_b; res[2] = o.over_a; res[3] = o.over_b;
+    res[4] = o.unfaithful_a; res[5] = o.unfaithful_b; res[6] = o.over_f_a; res[7] = o.over_f_b;
+    res[8] = o.worst_a; res[9] = o.worst_b;
+}
+
+void lab_sincos_half2(const float *x, size_t n, uint32_t *packed)
+{
+    for (size_t i = 0; i < n; i++) packed[i] = dcs_sincos_half2(x[i]);
 }
 
 /* res = {n_mismatch, max_ulp, first_bad_x_bits, n_signed_zero_diffs} */

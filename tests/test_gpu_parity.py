@@ -1078,3 +1078,73 @@ def test_fused_generate_and_beamform_dt(gpu, oracle):
     gpu.memcpy_dtoh(got, d_beams)
     assert np.abs(got - exp).max() <= 2e-5 * A + 1e-6
     g.close()
+
+
+def test_b16_arithmetic_form_device_equals_host_sweep(gpu, probes):
+    """The device evaluates dcs_sincos_half2 (math_mode bit 2) to the same bits as the host build swept exhaustively
+    in tests/test_numerics.py -- including the compiler's v_fma_mix{lo,hi}_f16 fusion of the last fma with the
+    conversion, which must round like fmaf-then-convert (8M arguments: a single-rounding fma would differ on ~2^-13
+    of them)."""
+    import ctypes
+    import subprocess
+    from pathlib import Path
+
+    lab_dir = Path(__file__).resolve().parent / "numerics"
+    assert subprocess.run(["make", "-C", str(lab_dir)], capture_output=True).returncode == 0
+    L = ctypes.CDLL(str(lab_dir / "libnumerics_lab.so"))
+    L.lab_sincos_half2.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+    rng = np.random.default_rng(2)
+    x = np.concatenate([
+        rng.uniform(-100, 100, 1 << 22).astype(np.float32),
+        rng.uniform(-500, 500, 1 << 21).astype(np.float32),
+        rng.uniform(-32000, 32000, 1 << 21).astype(np.float32),
+        (np.arange(1, 20000, dtype=np.float32) * np.float32(np.pi / 2)),
+        np.arange(0x3F800000, 0x3F800000 + (1 << 21), dtype=np.uint32).view(np.float32),  # a dense run of [1, 1.25)
+    ])
+    n = x.size
+    dx, dw = gpu.mem_alloc(4 * n), gpu.mem_alloc(4 * n)
+    gpu.memcpy_htod(dx, x)
+    probes.sincos(4, dx, n, dw, dw)
+    gpu.synchronize()
+    got = np.empty(n, np.uint32)
+    gpu.memcpy_dtoh(got, dw)
+    exp = np.empty(n, np.uint32)
+    L.lab_sincos_half2(x.ctypes.data, n, exp.ctypes.data)
+    bad = np.flatnonzero(got != exp)
+    assert bad.size == 0, (bad.size, x[bad[:4]], got[bad[:4]], exp[bad[:4]])
+
+
+@pytest.mark.parametrize("kernel", [1, 2])
+def test_b16_arithmetic_form_in_the_generator(gpu, oracle, kernel):
+    """math_mode = 4: b16 output from the binary16-sized arithmetic.  Every half within one binary16 ulp of
+    RN16(oracle fp32) (the bar the default b16 form is held to) -- also for pairs between 500 and 32000 rad; workgroups
+    holding a slow-class pair (|fRotation| >= 32000) keep the fp64 path and so reproduce the default output bit for bit;
+    fp32 output is unaffected."""
+    from dc_sand_amd import BeamformerParameters
+
+    def ordered(h):
+        i = h.view(np.int16).astype(np.int32)
+        return np.where(i < 0, -(i & 0x7FFF), i)
+
+    for (A, B, C) in ((64, 16, 64), (3, 5, 17), (2, 600, 40)):
+        bp = BeamformerParameters(NR_CHANNELS=C, NR_STATIONS=A, NR_BEAMS=B)
+        table = rand_table(bp.n_pairs, seed=C + 1)
+        if A == 2:
+            table["fPhase_rad"][0:100] = 2000.0     # full-degree class, still the b16 form
+            table["fPhase_rad"][600] = 40000.0      # slow class: the 256-pair tile 512..767 keeps the fp64 path
+        op = oracle.params_from(bp)
+        exp = oracle.generate(op, table, 5, 3).astype(np.float16)
+        dflt = _gen(gpu, bp, table, 5, 3, kernel=kernel, bitwidth=0)
+        fast = _gen(gpu, bp, table, 5, 3, kernel=kernel, bitwidth=0, tuning=dict(math_mode=4))
+        assert np.max(np.abs(ordered(fast) - ordered(exp))) <= 1
+        assert np.max(np.abs(ordered(dflt) - ordered(exp))) <= 1
+        differ = np.mean(fast.view(np.uint16) != dflt.view(np.uint16))
+        assert differ < 0.02, differ  # ~0.5 % of halves
+        if A == 2:
+            f = fast.reshape(3, C, bp.n_pairs, 2).view(np.uint16)
+            d = dflt.reshape(3, C, bp.n_pairs, 2).view(np.uint16)
+            assert np.array_equal(f[:, :, 512:768], d[:, :, 512:768])
+            assert not np.array_equal(f[:, :, 0:256], d[:, :, 0:256])
+        f32a = _gen(gpu, bp, table, 5, 3, kernel=kernel, bitwidth=1)
+        f32b = _gen(gpu, bp, table, 5, 3, kernel=kernel, bitwidth=1, tuning=dict(math_mode=4))
+        assert np.array_equal(f32a.view(np.uint32), f32b.view(np.uint32))
