@@ -110,6 +110,10 @@ struct dcs_bf_context {
     uint32_t terms_steps;   // time steps the table holds
     float *d_terms;         // [terms_steps][pairs_pad][2]; allocated on first use (ensure_terms)
     uint32_t *d_flags;      // [terms_steps][pairs_pad/64]
+    // the terms-table variant of the tiled form (large launches of <= kTermsInline time steps): its own small
+    // table, allocated with the context so that those launches stay capturable
+    float *d_tt_terms;      // [kTermsInline][pairs_pad][2]
+    uint32_t *d_tt_flags;   // [kTermsInline][pairs_pad/64]
     dcs_bf_tuning tune;     // the caller's explicit knobs (dcs_bf_set_tuning); 0 / -1 = not set
     // what dcs_bf_autotune measured for this context's shape, per output width [0] = fp32, [1] = fp16;
     // used for large launches wherever the caller has not set a knob explicitly
@@ -353,6 +357,8 @@ int dcs_bf_create(const dcs_bf_params *p, dcs_bf_context **out)
         if ((st = (int)hipMalloc((void **)&c->d_table[1], tb)) != 0) break;
         const size_t db = (size_t)kDtSlots * kDtSlotFloats * sizeof(float);
         if ((st = (int)hipMalloc((void **)&c->d_dt, db)) != 0) break;
+        if ((st = (int)hipMalloc((void **)&c->d_tt_terms, (size_t)kTermsInline * c->pairs_pad * 8u)) != 0) break;
+        if ((st = (int)hipMalloc((void **)&c->d_tt_flags, (size_t)kTermsInline * (c->pairs_pad / 64u) * 4u)) != 0) break;
         if ((st = (int)hipHostMalloc((void **)&c->h_dt, db, hipHostMallocDefault)) != 0) break;
         for (int i = 0; i < kDtSlots && st == 0; i++) st = (int)hipEventCreateWithFlags(&c->dt_ev[i], hipEventDisableTiming);
         if (st != 0) break;
@@ -379,6 +385,8 @@ int dcs_bf_destroy(dcs_bf_context *c)
     (void)hipFree(c->d_dt);
     (void)hipFree(c->d_terms);
     (void)hipFree(c->d_flags);
+    (void)hipFree(c->d_tt_terms);
+    (void)hipFree(c->d_tt_flags);
     if (c->h_dt) (void)hipHostFree(c->h_dt);
     for (int i = 0; i < kDtSlots; i++)
         if (c->dt_ev[i]) (void)hipEventDestroy(c->dt_ev[i]);
@@ -428,7 +436,7 @@ int dcs_bf_set_tuning(dcs_bf_context *c, const dcs_bf_tuning *t)
         c->tuned[0].valid = c->tuned[1].valid = false; // forget what dcs_bf_autotune measured, too
         return DCS_OK;
     }
-    if (t->form < 0 || t->form > 2) return DCS_ERR_INVALID_ARGUMENT;
+    if (t->form < 0 || t->form > 3) return DCS_ERR_INVALID_ARGUMENT;
     if (t->nontemporal < -1 || t->nontemporal > 1) return DCS_ERR_INVALID_ARGUMENT;
     if (t->chan_per_block < 0 || t->chan_per_block > (1 << 24)) return DCS_ERR_INVALID_ARGUMENT;
     if (t->tiles_per_block != 0 && t->tiles_per_block != 1 && t->tiles_per_block != 2 && t->tiles_per_block != 4)
@@ -539,8 +547,18 @@ uint32_t lds_pad_for(int k, bool out16, int tpb)
     return per > stat ? per - stat : 0u;
 }
 
+// Large launches of the tiled form read their pairs' terms from a table written by a pre-pass kernel instead
+// of computing them in every workgroup (bf_kernels.hip, TERMS): form 0 decides by size, form 1 never, form 3 always.
+bool want_terms_table(const dcs_bf_context *c, bool out16, const bf_geom &g, uint32_t nc, uint32_t nt)
+{
+    if (c->tune.probe_nomath || !g.ntstore || nt > kTermsInline) return false;
+    if (c->tune.form == 3) return true;
+    if (c->tune.form != 0) return false;
+    return tiled_blocks(c->n_pairs, out16, g.tpb, g.cpb, nc, nt) > 256u * 8u;
+}
+
 int prepare_tiled(dcs_bf_context *c, bool out16, const float *dt_dev, float dt0, uint32_t nt, uint32_t c0,
-                  uint32_t nc, void *d_out, bf_kernel_launch *l, const float *dt_host = nullptr)
+                  uint32_t nc, void *d_out, bf_kernel_launch *l, const float *dt_host = nullptr, bool terms_table = false)
 {
     bf_tiled_args a;
     std::memset(&a, 0, sizeof(a));
@@ -553,6 +571,11 @@ int prepare_tiled(dcs_bf_context *c, bool out16, const float *dt_dev, float dt0,
     a.nc = nc;
     a.nt = nt;
     a.k = c->k;
+    if (terms_table) {
+        a.terms = c->d_tt_terms;
+        a.flags = c->d_tt_flags;
+        a.pairs_pad = c->pairs_pad;
+    }
     const bf_geom g = pick_geometry(c, out16, nc, nt);
     const int tpb = g.tpb;
     const bool ntstore = g.ntstore;
@@ -569,8 +592,27 @@ int prepare_tiled(dcs_bf_context *c, bool out16, const float *dt_dev, float dt0,
 int launch_tiled(dcs_bf_context *c, bool out16, const float *dt_dev, float dt0, uint32_t nt, uint32_t c0,
                  uint32_t nc, void *d_out, hipStream_t stream, const float *dt_host = nullptr)
 {
+    const bool tt = dt_dev == nullptr && (nt == 1 || dt_host != nullptr) &&
+                    want_terms_table(c, out16, pick_geometry(c, out16, nc, nt), nc, nt);
+    if (tt) {
+        bf_terms_args ta;
+        std::memset(&ta, 0, sizeof(ta));
+        ta.delays = c->d_table[c->cur];
+        ta.terms = c->d_tt_terms;
+        ta.flags = c->d_tt_flags;
+        ta.dt_dev = nullptr;
+        ta.dt0 = dt0;
+        ta.dt_inline[0] = dt0;
+        if (nt > 1) std::memcpy(ta.dt_inline, dt_host, (size_t)nt * sizeof(float));
+        ta.n_pairs = c->n_pairs;
+        ta.pairs_pad = c->pairs_pad;
+        ta.nt = nt;
+        ta.k = c->k;
+        const hipError_t e = bf_launch_terms(ta, stream);
+        if (e != hipSuccess) return (int)e;
+    }
     bf_kernel_launch l;
-    int st = prepare_tiled(c, out16, dt_dev, dt0, nt, c0, nc, d_out, &l, dt_host);
+    int st = prepare_tiled(c, out16, dt_dev, dt0, nt, c0, nc, d_out, &l, dt_host, tt);
     if (st != DCS_OK || l.func == nullptr) return st;
     void *params[] = {&l.args};
     return (int)hipLaunchKernel(l.func, l.grid, l.block, params, l.shared, stream);
@@ -600,6 +642,7 @@ int launch_rows(dcs_bf_context *c, bool out16, const float *dt_dev, float dt0, u
     ta.flags = c->d_flags;
     ta.dt_dev = dt_dev;
     ta.dt0 = dt0;
+    ta.dt_inline[0] = dt0;
     ta.n_pairs = c->n_pairs;
     ta.pairs_pad = c->pairs_pad;
     ta.nt = nt;
@@ -641,7 +684,7 @@ int launch_form(dcs_bf_context *c, bool out16, const float *dt_dev, float dt0, u
                 uint32_t nc, void *d_out, hipStream_t stream)
 {
     const int form = c->tune.form ? c->tune.form : 1;
-    return form == 1 ? launch_tiled(c, out16, dt_dev, dt0, nt, c0, nc, d_out, stream)
+    return form != 2 ? launch_tiled(c, out16, dt_dev, dt0, nt, c0, nc, d_out, stream)
                      : launch_rows(c, out16, dt_dev, dt0, nt, c0, nc, d_out, stream);
 }
 
@@ -700,7 +743,7 @@ int generate_slab_impl(dcs_bf_context *c, int bitwidth, const dt_source &src, ui
             float dt;
             if ((st = fill_dt(c, src, done, 1, &dt)) != DCS_OK) return st;
             st = launch_form(c, out16, nullptr, dt, 1, c0, nc, dst, s);
-        } else if ((c->tune.form == 0 || c->tune.form == 1) && n <= kDtInline) {
+        } else if (c->tune.form != 2 && n <= kDtInline) {
             // tiled form, few time steps: their dt values ride in the kernel arguments (no copy in front)
             float dts[kDtInline];
             if ((st = fill_dt(c, src, done, n, dts)) != DCS_OK) return st;
@@ -916,7 +959,6 @@ int dcs_bf_autotune(dcs_bf_context *c, int bitwidth, void *d_out, size_t out_byt
     auto report = [&]() {
         if (!chosen) return;
         *chosen = c->tune;
-        chosen->form = 1;
         chosen->tiles_per_block = slot.tpb;
         chosen->chan_per_block = slot.cpb;
         chosen->wg_per_cu = slot.wpc;
@@ -955,7 +997,7 @@ int dcs_bf_autotune(dcs_bf_context *c, int bitwidth, void *d_out, size_t out_byt
     const dcs_bf_tuning saved = c->tune;
     c->tuning_now = true;
     auto use = [&](const cand &k) {
-        c->tune.form = 1;
+        c->tune.form = saved.form == 2 ? 0 : saved.form; // the tiled form as production launches will run it
         c->tune.tiles_per_block = k.tpb;
         c->tune.chan_per_block = k.cpb;
         c->tune.wg_per_cu = k.wpc;

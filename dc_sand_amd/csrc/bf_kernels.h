@@ -26,6 +26,10 @@ struct bf_tiled_args {
     uint32_t pace;                // probes build only: 64-cycle sleeps before each store of the fast loop
 #endif
     dcs_bf_consts k;
+    // terms-table variant (nullptr: the workgroups compute and stage their pairs' terms themselves):
+    const float *terms;           // [nt][pairs_pad][2], written by bf_launch_terms just before
+    const uint32_t *flags;        // [nt][pairs_pad/64]
+    uint32_t pairs_pad;
 };
 // The same with fDeltaTime of up to kDtInline time steps by value (kernel arguments): the reference's
 // default tensor (256 time steps, 134 MB) is a 22 us kernel, and a pinned->device copy of the dt table
@@ -56,11 +60,13 @@ struct bf_terms_args {
     const dcs_delay_vals *delays; // [n_pairs]
     float *terms;                 // [nt][pairs_pad][2]
     uint32_t *flags;              // [nt][pairs_pad/64]
-    const float *dt_dev;          // or nullptr -> dt0, nt == 1
+    const float *dt_dev;          // or nullptr -> dt_inline (nt <= kTermsInline; dt_inline[0] == dt0)
     float dt0;
     uint32_t n_pairs, pairs_pad, nt;
     dcs_bf_consts k;
+    float dt_inline[8];
 };
+constexpr uint32_t kTermsInline = 8;
 hipError_t bf_launch_terms(const bf_terms_args &a, hipStream_t stream);
 
 struct bf_rows_args {

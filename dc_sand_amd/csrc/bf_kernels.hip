@@ -118,7 +118,13 @@ __device__ __forceinline__ uint32_t pack_half2(const float re, const float im)
 //             production launches are not mixed with the tuner's trial geometries
 // ---------------------------------------------------------------------------
 //   INL     : the kernel parameter is bf_tiled_args_inl (fDeltaTime of up to 256 time steps by value)
-template <bool OUT16, int TPB, bool NT, bool ALIGNED, bool NOMATH, int TAG = 0, bool INL = false>
+//   TERMS   : the pairs' channel-independent terms and classes come from the table bf_terms_kernel wrote
+//             just before (a.terms / a.flags) instead of being computed and staged in LDS by every
+//             workgroup: no fp64, no LDS, no barrier in this kernel.  The per-workgroup set-up is ~70
+//             VALU issue slots per lane (the fp64 chain with its divide, the class bound) against the
+//             6 (fp32) to 48 (fp16) coefficients a lane then produces on a short walk: 12 of the fp32
+//             kernel's 41.6 lane-operations per coefficient.  Large launches take this variant.
+template <bool OUT16, int TPB, bool NT, bool ALIGNED, bool NOMATH, int TAG = 0, bool INL = false, bool TERMS = false>
 __global__ void __launch_bounds__(kBlock) bf_tiled_kernel(const std::conditional_t<INL, bf_tiled_args_inl, bf_tiled_args> args)
 {
     const bf_tiled_args &a = [&]() -> const bf_tiled_args & {
@@ -133,8 +139,6 @@ __global__ void __launch_bounds__(kBlock) bf_tiled_kernel(const std::conditional
     constexpr uint32_t EB = OUT16 ? 4u : 8u; // bytes per coefficient
     constexpr int kSlowUnroll = OUT16 ? 1 : PPL; // unrolling of the slow path's pair loop (see there)
 
-    __shared__ __attribute__((aligned(16))) float s_terms[TPB * TILE * 2]; // {fRateTerm, fPhase0}
-
     // workgroup -> (tile group, channel block, time step); tile group fastest so
     // that concurrently resident workgroups cover one channel row end to end.
     uint32_t bid = blockIdx.x;
@@ -143,30 +147,7 @@ __global__ void __launch_bounds__(kBlock) bf_tiled_kernel(const std::conditional
     const uint32_t rest = bid / a.n_tile_groups;
     const uint32_t cb = rest % a.n_cblocks;
     const uint32_t t = rest / a.n_cblocks;
-
-    float dt;
-    if constexpr (INL)
-        dt = a.dt_dev ? a.dt_dev[t] : args.dt_inline[t];
-    else
-        dt = a.dt_dev ? a.dt_dev[t] : a.dt0;
     const uint32_t pair_base = tg * (uint32_t)(TPB * TILE);
-
-    // ---- stage the channel-independent terms of this workgroup's pairs in LDS
-    for (uint32_t i = threadIdx.x; i < (uint32_t)(TPB * TILE); i += kBlock) {
-        const uint32_t p = pair_base + i;
-        float fRate = 0.0f, fPhase0 = 0.0f;
-        if (p < a.n_pairs) {
-            const floatx4 raw = *reinterpret_cast<const floatx4 *>(&a.delays[p]);
-            dcs_delay_vals d;
-            d.fDelay_s = raw.x;
-            d.fDelayRate_sps = raw.y;
-            d.fPhase_rad = raw.z;
-            d.fPhaseRate_radps = raw.w;
-            dcs_pair_terms(d, dt, a.k.dHalfChannels, a.k.dDenominator, &fRate, &fPhase0);
-        }
-        *reinterpret_cast<floatx2 *>(&s_terms[2 * i]) = floatx2{fRate, fPhase0};
-    }
-    __syncthreads();
 
     const uint32_t wave = threadIdx.x >> 6;
     const uint32_t lane = threadIdx.x & 63u;
@@ -176,19 +157,69 @@ __global__ void __launch_bounds__(kBlock) bf_tiled_kernel(const std::conditional
     const uint32_t p0 = pair_base + li;
 
     float fRate[PPL], fPhase0[PPL];
-    uint32_t cls = DCS_CLASS_FAST_LOW;
+    bool wave_slow, wave_low;
+    if constexpr (TERMS) {
+        // ---- terms and classes from the pre-pass table ([t][pairs_pad]; pairs past n_pairs hold zeros)
+        const uint32_t wave_p0 = pair_base + tile * (uint32_t)TILE; // wave-uniform
+        uint32_t cls = DCS_CLASS_FAST_LOW;
+        if (wave_p0 < a.pairs_pad) {
+            const uint32_t *fl = a.flags + (uint64_t)t * (a.pairs_pad / 64u) + wave_p0 / 64u;
 #pragma unroll
-    for (int j = 0; j < PPL; j += 2) {
-        const floatx4 v = *reinterpret_cast<const floatx4 *>(&s_terms[2 * (li + j)]);
-        fRate[j] = v.x;
-        fPhase0[j] = v.y;
-        fRate[j + 1] = v.z;
-        fPhase0[j + 1] = v.w;
+            for (int j = 0; j < TILE / 64; j++)
+                if (wave_p0 + 64u * (uint32_t)j < a.pairs_pad) cls = max(cls, fl[j]);
+        }
+        cls = __builtin_amdgcn_readfirstlane(cls);
+        wave_slow = cls == DCS_CLASS_SLOW;
+        wave_low = cls == DCS_CLASS_FAST_LOW;
+        if (p0 >= a.n_pairs) return; // pairs_pad >= n_pairs: every load below is inside the table
+        const floatx4 *tp = reinterpret_cast<const floatx4 *>(a.terms + 2u * ((uint64_t)t * a.pairs_pad + p0));
+#pragma unroll
+        for (int j = 0; j < PPL; j += 2) {
+            const floatx4 v = tp[j / 2];
+            fRate[j] = v.x;
+            fPhase0[j] = v.y;
+            fRate[j + 1] = v.z;
+            fPhase0[j + 1] = v.w;
+        }
+    } else {
+        __shared__ __attribute__((aligned(16))) float s_terms[TPB * TILE * 2]; // {fRateTerm, fPhase0}
+        float dt;
+        if constexpr (INL)
+            dt = a.dt_dev ? a.dt_dev[t] : args.dt_inline[t];
+        else
+            dt = a.dt_dev ? a.dt_dev[t] : a.dt0;
+
+        // ---- stage the channel-independent terms of this workgroup's pairs in LDS
+        for (uint32_t i = threadIdx.x; i < (uint32_t)(TPB * TILE); i += kBlock) {
+            const uint32_t p = pair_base + i;
+            float fR = 0.0f, fP = 0.0f;
+            if (p < a.n_pairs) {
+                const floatx4 raw = *reinterpret_cast<const floatx4 *>(&a.delays[p]);
+                dcs_delay_vals d;
+                d.fDelay_s = raw.x;
+                d.fDelayRate_sps = raw.y;
+                d.fPhase_rad = raw.z;
+                d.fPhaseRate_radps = raw.w;
+                dcs_pair_terms(d, dt, a.k.dHalfChannels, a.k.dDenominator, &fR, &fP);
+            }
+            *reinterpret_cast<floatx2 *>(&s_terms[2 * i]) = floatx2{fR, fP};
+        }
+        __syncthreads();
+
+        uint32_t cls = DCS_CLASS_FAST_LOW;
+#pragma unroll
+        for (int j = 0; j < PPL; j += 2) {
+            const floatx4 v = *reinterpret_cast<const floatx4 *>(&s_terms[2 * (li + j)]);
+            fRate[j] = v.x;
+            fPhase0[j] = v.y;
+            fRate[j + 1] = v.z;
+            fPhase0[j + 1] = v.w;
+        }
+#pragma unroll
+        for (int j = 0; j < PPL; j++) cls = max(cls, dcs_pair_class(fRate[j], fPhase0[j], a.k.fRotBoundScale, a.k.fLowDegLimit));
+        wave_slow = __builtin_amdgcn_ballot_w64(cls == DCS_CLASS_SLOW) != 0ull;
+        wave_low = __builtin_amdgcn_ballot_w64(cls != DCS_CLASS_FAST_LOW) == 0ull;
     }
-#pragma unroll
-    for (int j = 0; j < PPL; j++) cls = max(cls, dcs_pair_class(fRate[j], fPhase0[j], a.k.fRotBoundScale, a.k.fLowDegLimit));
-    const bool wave_slow = __builtin_amdgcn_ballot_w64(cls == DCS_CLASS_SLOW) != 0ull;
-    const bool wave_low = __builtin_amdgcn_ballot_w64(cls != DCS_CLASS_FAST_LOW) == 0ull;
 
     const uint32_t cbeg = cb * a.chan_per_block;
     const uint32_t cend = min(cbeg + a.chan_per_block, a.nc);
@@ -430,7 +461,7 @@ __global__ void __launch_bounds__(kBlock) bf_terms_kernel(const bf_terms_args a)
 {
     const uint32_t p = blockIdx.x * kBlock + threadIdx.x; // < pairs_pad (grid exact)
     const uint32_t t = blockIdx.y;
-    const float dt = a.dt_dev ? a.dt_dev[t] : a.dt0;
+    const float dt = a.dt_dev ? a.dt_dev[t] : a.dt_inline[t];
     float fRate = 0.0f, fPhase0 = 0.0f;
     if (p < a.n_pairs) {
         const floatx4 raw = *reinterpret_cast<const floatx4 *>(&a.delays[p]);
@@ -668,8 +699,17 @@ __global__ void __launch_bounds__(kBlock) bf_gather_beams_kernel(dcs_delay_vals 
 }
 
 template <bool OUT16, int TPB, bool NT, bool ALIGNED>
-const void *tiled_fn_nm(bool nomath, bool tuner, bool inl)
+const void *tiled_fn_nm(bool nomath, bool tuner, bool inl, bool terms)
 {
+    if (terms) { // the terms-table variant exists with nontemporal stores only (the default policy)
+        if constexpr (NT) {
+            if (inl || nomath) return nullptr;
+            return tuner ? reinterpret_cast<const void *>(&bf_tiled_kernel<OUT16, TPB, NT, ALIGNED, false, 1, false, true>)
+                         : reinterpret_cast<const void *>(&bf_tiled_kernel<OUT16, TPB, NT, ALIGNED, false, 0, false, true>);
+        } else {
+            return nullptr;
+        }
+    }
     if (inl) return (nomath || tuner) ? nullptr : reinterpret_cast<const void *>(&bf_tiled_kernel<OUT16, TPB, NT, ALIGNED, false, 0, true>);
     if (tuner) return reinterpret_cast<const void *>(&bf_tiled_kernel<OUT16, TPB, NT, ALIGNED, false, 1>);
 #ifdef DCS_PROBES
@@ -681,19 +721,19 @@ const void *tiled_fn_nm(bool nomath, bool tuner, bool inl)
 }
 
 template <bool OUT16, int TPB>
-const void *tiled_fn_t(bool nt, bool aligned, bool nomath, bool tuner, bool inl)
+const void *tiled_fn_t(bool nt, bool aligned, bool nomath, bool tuner, bool inl, bool terms)
 {
-    if (nt) return aligned ? tiled_fn_nm<OUT16, TPB, true, true>(nomath, tuner, inl) : tiled_fn_nm<OUT16, TPB, true, false>(nomath, tuner, inl);
-    return aligned ? tiled_fn_nm<OUT16, TPB, false, true>(nomath, tuner, inl) : tiled_fn_nm<OUT16, TPB, false, false>(nomath, tuner, inl);
+    if (nt) return aligned ? tiled_fn_nm<OUT16, TPB, true, true>(nomath, tuner, inl, terms) : tiled_fn_nm<OUT16, TPB, true, false>(nomath, tuner, inl, terms);
+    return aligned ? tiled_fn_nm<OUT16, TPB, false, true>(nomath, tuner, inl, terms) : tiled_fn_nm<OUT16, TPB, false, false>(nomath, tuner, inl, terms);
 }
 
 template <bool OUT16>
-const void *tiled_fn_o(int tpb, bool nt, bool aligned, bool nomath, bool tuner, bool inl)
+const void *tiled_fn_o(int tpb, bool nt, bool aligned, bool nomath, bool tuner, bool inl, bool terms)
 {
     switch (tpb) {
-    case 1: return tiled_fn_t<OUT16, 1>(nt, aligned, nomath, tuner, inl);
-    case 2: return tiled_fn_t<OUT16, 2>(nt, aligned, nomath, tuner, inl);
-    case 4: return tiled_fn_t<OUT16, 4>(nt, aligned, nomath, tuner, inl);
+    case 1: return tiled_fn_t<OUT16, 1>(nt, aligned, nomath, tuner, inl, terms);
+    case 2: return tiled_fn_t<OUT16, 2>(nt, aligned, nomath, tuner, inl, terms);
+    case 4: return tiled_fn_t<OUT16, 4>(nt, aligned, nomath, tuner, inl, terms);
     default: return nullptr;
     }
 }
@@ -717,13 +757,15 @@ hipError_t bf_prepare_tiled(const bf_tiled_args &a_in, const float *dt_inline, b
     a.n_cblocks = (a.nc + a.chan_per_block - 1) / a.chan_per_block;
     const uint64_t blocks = (uint64_t)a.n_tile_groups * a.n_cblocks * a.nt;
     if (blocks == 0 || blocks > 0x7fffffffull) return hipErrorInvalidValue;
-    const bool inl = a.dt_dev == nullptr && a.nt > 1;
+    const bool terms = a.terms != nullptr; // the terms-table variant: fDeltaTime went into bf_launch_terms instead
+    if (terms && (a.flags == nullptr || a.pairs_pad < a.n_pairs || (a.pairs_pad % 256u))) return hipErrorInvalidValue;
+    const bool inl = !terms && a.dt_dev == nullptr && a.nt > 1;
     if (inl && (dt_inline == nullptr || a.nt > kDtInline)) return hipErrorInvalidValue;
     if (inl) std::memcpy(out->args.dt_inline, dt_inline, (size_t)a.nt * sizeof(float));
     if (blocks % 8u) a.xcd_remap = 0; // the renumbering is a bijection only then
     const bool aligned = (a.n_pairs % ppl) == 0 && (reinterpret_cast<uintptr_t>(a.out) % 16u) == 0;
-    const void *fn = out16 ? tiled_fn_o<true>(tiles_per_block, nontemporal, aligned, nomath, tuner, inl)
-                           : tiled_fn_o<false>(tiles_per_block, nontemporal, aligned, nomath, tuner, inl);
+    const void *fn = out16 ? tiled_fn_o<true>(tiles_per_block, nontemporal, aligned, nomath, tuner, inl, terms)
+                           : tiled_fn_o<false>(tiles_per_block, nontemporal, aligned, nomath, tuner, inl, terms);
     if (!fn) return hipErrorInvalidValue;
     out->func = fn;
     out->grid = dim3((uint32_t)blocks);
@@ -805,7 +847,7 @@ hipError_t bf_launch_terms(const bf_terms_args &a, hipStream_t stream)
 {
     if (a.nt == 0 || a.pairs_pad == 0) return hipSuccess;
     if (a.pairs_pad % kBlock || a.nt > 65535u) return hipErrorInvalidValue;
-    if (a.dt_dev == nullptr && a.nt != 1) return hipErrorInvalidValue;
+    if (a.dt_dev == nullptr && a.nt > kTermsInline) return hipErrorInvalidValue;
     const dim3 grid(a.pairs_pad / kBlock, a.nt);
     hipLaunchKernelGGL(bf_terms_kernel, grid, dim3(kBlock), 0, stream, a);
     return hipGetLastError();

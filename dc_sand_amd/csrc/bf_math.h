@@ -324,8 +324,16 @@ DCS_HD uint32_t dcs_sincos_half2(const float x)
     const float s = r * r;
     const float ps = dcs_fmaf(s, DCS_HS2, DCS_HS1);
     const float pc = dcs_fmaf(s, DCS_HC1, DCS_HC0);
-    const float sr = dcs_fmaf(s * r, ps, r);
-    const float cr = dcs_fmaf(s, pc, 1.0f);
+    float sr = dcs_fmaf(s * r, ps, r);
+    float cr = dcs_fmaf(s, pc, 1.0f);
+#if defined(__HIP_DEVICE_COMPILE__)
+    // Keep the two fmas fp32 instructions and the conversion ONE v_cvt_pk_f16_f32.  Left alone, hipcc fuses each
+    // fma with its conversion into v_fma_mixlo_f16 / v_fma_mixhi_f16, which (measured on MI355X) round the exact
+    // fma result straight to binary16 -- 1.3e-4 of the arguments then differ from the fmaf-then-convert sequence
+    // the host sweep proves -- and issue so slowly that the 22-instruction loop ran 4 % slower than the
+    // 28-instruction fp32-then-round form (profiles/r02_fp16.md).
+    asm("" : "+v"(sr), "+v"(cr));
+#endif
     const uint32_t p = dcs_pack_half2(cr, sr);
     // n mod 4:  0: (cr, sr)  1: (-sr, cr)  2: (-cr, -sr)  3: (sr, -cr)   as (cos, sin)
     const uint32_t amt = q << 4; // bit 4 = n mod 2: rotate the halves by 16 when n is odd

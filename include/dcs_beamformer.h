@@ -227,14 +227,21 @@ int dcs_bf_generate_and_beamform_dt(dcs_bf_context *ctx, const float *dt, uint32
  * launch-bound tensors of <= 32 MiB; fp16: 128 channels, fewer while the chip would be left under 2048
  * workgroups; no residency limit when every workgroup is resident at once).  Two forms of the
  * MULTIPLE_CHANNELS_AND_TIMESTAMPS generator exist and give identical bits:
- *   form 1 "tiled": a workgroup keeps its pairs' terms in registers and walks
- *           chan_per_block channels (tiles_per_block 1-KiB tiles wide);
- *   form 2 "rows":  a small terms table is written first, then short waves
+ *   "tiled": a workgroup (4 waves) keeps its pairs' terms in registers and walks chan_per_block
+ *           channels, tiles_per_block 1-KiB tiles wide.  The terms (one fp64 chain per pair and time
+ *           step) are either computed by every workgroup and staged in LDS (form 1), or read from a
+ *           small table a pre-pass kernel writes just before (form 3; at most 8 time steps per launch,
+ *           nontemporal stores): the pre-pass costs ~3 us and takes ~12 of 41 VALU operations per fp32
+ *           coefficient out of the main kernel.  form 0 (default) picks by size: the table for launches
+ *           that oversubscribe the chip, per-workgroup terms for small ones (and always inside
+ *           dcs_bf_stream_* graphs, which hold one kernel node);
+ *   form 2 "rows":  the terms table for any number of time steps, then short waves
  *           (waves_per_block adjacent 1-KiB tiles x rows_per_wave channel rows)
  *           stream the tensor in address order.
- * MULTIPLE_CHANNELS always uses form 1 (the reference's per-time-step shape). */
+ * MULTIPLE_CHANNELS always uses the tiled form (the reference's per-time-step shape). */
 struct dcs_bf_tuning {
-    int32_t form;            /* 0 default, 1 tiled, 2 rows */
+    int32_t form;            /* 0 default (tiled; terms table for large launches), 1 tiled with per-workgroup terms,
+                              * 2 rows, 3 tiled with the terms table */
     int32_t nontemporal;     /* -1 default, 0 plain stores, 1 nontemporal */
     int32_t chan_per_block;  /* form 1 */
     int32_t tiles_per_block; /* form 1: 1, 2, 4 */
@@ -251,7 +258,7 @@ struct dcs_bf_tuning {
                               * proven.  Bit 2 (value 4) OPTS IN to the b16 arithmetic form: where the output is b16
                               * and no pair of a wave needs the slow path (|fRotation| < 32000), sin and cos are evaluated to binary16
                               * accuracy (two-term reduction, degree 5 / 4) and converted once, instead of rounding the
-                              * 1-ULP fp32 pair: 22 instead of 28 VALU operations per coefficient.  Every half is within
+                              * 1-ULP fp32 pair: 23 instead of 28 VALU operations per coefficient.  Every half is within
                               * one binary16 ulp of RN16(correctly rounded value) for EVERY fp32 argument below 32768, and
                               * equal to it for 99.8 % of them (0.9 % differ in [1, 32768); tests/test_numerics.py, by
                               * exhaustion).  The reference rounds whatever __sincosf returned and never checks it

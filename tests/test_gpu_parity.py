@@ -155,6 +155,10 @@ TUNINGS = [
     dict(form=1, tiles_per_block=1, chan_per_block=12, wg_per_cu=-1),
     dict(form=1, tiles_per_block=2, chan_per_block=5, wg_per_cu=2),
     dict(form=1, tiles_per_block=4, chan_per_block=9, wg_per_cu=7),
+    dict(form=3),
+    dict(form=3, tiles_per_block=2, chan_per_block=5, wg_per_cu=-1),
+    dict(form=3, tiles_per_block=4, chan_per_block=3, wg_per_cu=7),
+    dict(form=3, tiles_per_block=1, chan_per_block=16, nontemporal=0),
     dict(form=2),
     dict(form=2, waves_per_block=4, rows_per_wave=1, rows_same_tile=0),
     dict(form=2, waves_per_block=4, rows_per_wave=2, nontemporal=1, rows_same_tile=0),
@@ -227,7 +231,7 @@ def test_slow_path_large_rotation_and_extreme_rates(gpu, oracle):
     table["fDelay_s"][201] = 1.0
     op = oracle.params_from(bp)
     for t in (0, 9):
-        for form in (1, 2):
+        for form in (1, 2, 3):
             got = _gen(gpu, bp, table, t, 1, tuning=dict(form=form))
             _check(oracle, got, oracle.generate(op, table, t, 1), tol=1e-4)
 
@@ -279,7 +283,7 @@ def test_error_behaviour(gpu):
     with pytest.raises(_lib.DcsError) as e:
         g.generate(buf, buf.nbytes - 1)
     assert e.value.status == _lib.DCS_ERR_INVALID_ARGUMENT
-    for bad in (dict(wg_per_cu=1), dict(wg_per_cu=8), dict(wg_per_cu=-2), dict(tiles_per_block=3), dict(form=3), dict(math_mode=-1)):
+    for bad in (dict(wg_per_cu=1), dict(wg_per_cu=8), dict(wg_per_cu=-2), dict(tiles_per_block=3), dict(form=4), dict(math_mode=-1)):
         with pytest.raises(_lib.DcsError) as e:
             g.set_tuning(**bad)
         assert e.value.status == _lib.DCS_ERR_INVALID_ARGUMENT, bad
@@ -644,7 +648,7 @@ def test_cpp_host_against_c_abi(gpu):
         assert name in run.stdout
 
 
-@pytest.mark.parametrize("form", [1, 2])
+@pytest.mark.parametrize("form", [1, 2, 3])
 def test_arithmetic_forms_agree_and_class_boundaries(gpu, oracle, form):
     """The fast path has four arithmetic forms (3-op / 5-op divide x low- / full-degree
     polynomials), chosen per wave from a bound on |fRotation|; all must give the
@@ -694,7 +698,7 @@ def test_autotune_keeps_results(gpu, oracle):
         t0 = time.perf_counter()
         chosen = g.autotune(buf, nbytes, bitwidth=bw)
         t_first = time.perf_counter() - t0
-        assert chosen["form"] == 1 and chosen["tiles_per_block"] in (1, 2, 4) and chosen["chan_per_block"] >= 1
+        assert chosen["form"] == 0 and chosen["tiles_per_block"] in (1, 2, 4) and chosen["chan_per_block"] >= 1
         t0 = time.perf_counter()
         again = g.autotune(buf, nbytes, bitwidth=bw)  # cached in the context per output width
         assert again == chosen and time.perf_counter() - t0 < 0.25 * t_first
@@ -738,7 +742,7 @@ def test_many_time_steps_cross_the_internal_chunking(gpu, oracle, form):
     _check(oracle, got, oracle.generate(op, table, 250, 5000))
 
 
-@pytest.mark.parametrize("form", [1, 2])
+@pytest.mark.parametrize("form", [1, 2, 3])
 @pytest.mark.parametrize("bitwidth", [1, 0])
 def test_output_pointer_not_16_byte_aligned(gpu, oracle, form, bitwidth):
     """An output tensor that starts 8 (fp32) or 4 (fp16) bytes off a 16-byte boundary
@@ -862,9 +866,9 @@ def test_seeded_fuzz_of_shapes_slabs_time_ranges_and_geometries(gpu, oracle):
         bp = BeamformerParameters(NR_CHANNELS=C, NR_STATIONS=A, NR_BEAMS=B)
         table = rand_table(bp.n_pairs, seed=1000 + case)
         bitwidth = int(rng.integers(0, 2))
-        form = int(rng.integers(1, 3))
-        if form == 1:
-            tuning = dict(form=1, tiles_per_block=int(rng.choice([1, 2, 4])), chan_per_block=int(rng.integers(1, 40)),
+        form = int(rng.integers(1, 4))
+        if form != 2:
+            tuning = dict(form=form if case % 3 else 0, tiles_per_block=int(rng.choice([1, 2, 4])), chan_per_block=int(rng.integers(1, 40)),
                           nontemporal=int(rng.integers(0, 2)), wg_per_cu=int(rng.choice([-1, 0, 2, 5, 6, 7])))
         else:
             tuning = dict(form=2, waves_per_block=int(rng.choice([4, 8, 16])), rows_per_wave=int(rng.integers(1, 5)),
@@ -872,7 +876,7 @@ def test_seeded_fuzz_of_shapes_slabs_time_ranges_and_geometries(gpu, oracle):
         use_slab = bool(rng.integers(0, 2))
         c0 = int(rng.integers(0, C)) if use_slab else 0
         nc = int(rng.integers(1, C - c0 + 1)) if use_slab else C
-        kernel = 2 if (use_slab or form == 2) else int(rng.choice([1, 2]))
+        kernel = 2 if (use_slab or form == 2) else int(rng.choice([1, 2]))  # (MULTIPLE_CHANNELS: the tiled form, one launch per time step)
         eb = 8 if bitwidth == 1 else 4
         off = int(rng.choice([0, eb, 16]))
         nbytes = nt * nc * bp.n_pairs * eb
@@ -1136,6 +1140,8 @@ def test_b16_arithmetic_form_in_the_generator(gpu, oracle, kernel):
         exp = oracle.generate(op, table, 5, 3).astype(np.float16)
         dflt = _gen(gpu, bp, table, 5, 3, kernel=kernel, bitwidth=0)
         fast = _gen(gpu, bp, table, 5, 3, kernel=kernel, bitwidth=0, tuning=dict(math_mode=4))
+        fast_tt = _gen(gpu, bp, table, 5, 3, kernel=kernel, bitwidth=0, tuning=dict(math_mode=4, form=3))  # terms from the pre-pass table
+        assert np.array_equal(fast.view(np.uint16), fast_tt.view(np.uint16))
         assert np.max(np.abs(ordered(fast) - ordered(exp))) <= 1
         assert np.max(np.abs(ordered(dflt) - ordered(exp))) <= 1
         differ = np.mean(fast.view(np.uint16) != dflt.view(np.uint16))

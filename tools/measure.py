@@ -176,12 +176,22 @@ def cmd_fp16(args):
     bp, g, _, _, buf = make(SHAPES["cfg3"], 32)
     n = bp.coeffs_per_time_step()
     nb16 = g.output_bytes(0, 1)
+    res = []
     for mode in [int(m) for m in args.modes.split(",")]:
-        for cpb in [int(c) for c in args.cpb.split(",")]:
-            g.set_tuning(form=1, tiles_per_block=1, chan_per_block=cpb, nontemporal=1, math_mode=mode, wg_per_cu=args.wpc)
-            ms = min(per_launch_ms(lambda: g.generate(buf, nb16, t0=1, nt=1, bitwidth=0)) for _ in range(2))
-            print(f"fp16 math_mode={mode} cpb={cpb} wpc={args.wpc}: {ms:.4f} ms -> {n / ms / 1e6:.1f} Gcoeff/s = {nb16 / ms / 1e9:.2f} TB/s "
-                  f"({nb16 / ms / 1e9 / 8 * 100:.1f} % of 8 TB/s)", flush=True)
+        for tpb in [int(c) for c in args.tpb.split(",")]:
+            for wpc in [int(c) for c in args.wpc.split(",")]:
+                for cpb in [int(c) for c in args.cpb.split(",")]:
+                    g.set_tuning(form=1, tiles_per_block=tpb, chan_per_block=cpb, nontemporal=1, math_mode=mode, wg_per_cu=wpc)
+                    ms = min(per_launch_ms(lambda: g.generate(buf, nb16, t0=1, nt=1, bitwidth=0)) for _ in range(2))
+                    res.append((ms, mode, tpb, wpc, cpb))
+                    print(f"fp16 math_mode={mode} tpb={tpb} cpb={cpb} wpc={wpc}: {ms:.4f} ms -> {n / ms / 1e6:.1f} Gcoeff/s = {nb16 / ms / 1e9:.2f} TB/s "
+                          f"({nb16 / ms / 1e9 / 8 * 100:.1f} % of 8 TB/s)", flush=True)
+    for mode in sorted({r[1] for r in res}):
+        b = min(r for r in res if r[1] == mode)
+        print(f"best math_mode={mode}: tpb={b[2]} cpb={b[4]} wpc={b[3]} -> {n / b[0] / 1e6:.1f} Gcoeff/s", flush=True)
+    g.set_tuning(math_mode=int(args.modes.split(",")[-1]))
+    ms = min(per_launch_ms(lambda: g.generate(buf, nb16, t0=1, nt=1, bitwidth=0)) for _ in range(2))
+    print(f"library default geometry, math_mode={args.modes.split(',')[-1]}: {n / ms / 1e6:.1f} Gcoeff/s", flush=True)
     g.close()
 
 
@@ -358,7 +368,8 @@ def main():
     p = sub.add_parser("fp16")
     p.add_argument("--modes", default="0,4")
     p.add_argument("--cpb", default="64,128,256")
-    p.add_argument("--wpc", type=int, default=0)
+    p.add_argument("--wpc", default="-1")
+    p.add_argument("--tpb", default="1")
     sub.add_parser("fused")
     p = sub.add_parser("stream")
     p.add_argument("--model-step-us", type=float, default=200.0)
