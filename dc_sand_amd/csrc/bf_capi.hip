@@ -447,6 +447,7 @@ int dcs_bf_set_tuning(dcs_bf_context *c, const dcs_bf_tuning *t)
     if (t->rows_same_tile < -1 || t->rows_same_tile > 1) return DCS_ERR_INVALID_ARGUMENT;
     if (t->xcd_remap < -1 || t->xcd_remap > 1) return DCS_ERR_INVALID_ARGUMENT;
     if (t->math_mode < 0 || t->math_mode > 7) return DCS_ERR_INVALID_ARGUMENT;
+    if ((t->math_mode & 4) && t->nontemporal == 0) return DCS_ERR_UNSUPPORTED; // the b16 arithmetic form exists with nontemporal stores only
 #ifdef DCS_PROBES
     if (t->probe_pace < 0 || t->probe_pace > 4096) return DCS_ERR_INVALID_ARGUMENT;
 #else
@@ -491,30 +492,54 @@ uint64_t tiled_blocks(uint32_t n_pairs, bool out16, int tpb, uint32_t cpb, uint3
     return (uint64_t)((n_pairs + ppb - 1) / ppb) * ((nc + cpb - 1) / cpb) * nt;
 }
 
+// Large launches of the tiled form read their pairs' terms from a table written by a pre-pass kernel instead
+// of computing them in every workgroup (bf_kernels.hip, TERMS): form 0 decides by size, form 1 never, form 3 always.
+bool want_terms_table(const dcs_bf_context *c, bool out16, const bf_geom &g, uint32_t nc, uint32_t nt)
+{
+    if (c->tune.probe_nomath || !g.ntstore || nt > kTermsInline) return false;
+    if (c->tune.form == 3) return true;
+    if (c->tune.form != 0) return false;
+    return tiled_blocks(c->n_pairs, out16, g.tpb, g.cpb, nc, nt) > 256u * 8u;
+}
+
 bf_geom shape_default_geometry(const dcs_bf_context *c, bool out16, uint32_t nc, uint32_t nt)
 {
     constexpr uint64_t kResident = 256u * 8u; // workgroups of 256 threads the chip holds at once
     bf_geom g;
-    g.ntstore = true;
+    g.ntstore = c->tune.nontemporal < 0 ? true : c->tune.nontemporal != 0;
     g.tpb = 1;
+    const bool half = out16 && c->k.uHalfMath != 0u;
     if (out16) {
         g.cpb = 128u;
         g.wpc = 0;
         while (g.cpb > 16u && tiled_blocks(c->n_pairs, true, 1, g.cpb, nc, nt) < kResident) g.cpb >>= 1;
-        return g;
+    } else {
+        g.cpb = 12u;
+        g.wpc = 6;
+        const uint32_t tiles = (c->n_pairs + 127u) / 128u;
+        if (tiles >= 2048u) {
+            g.cpb = 10u;
+            g.wpc = 0;
+        }
+        const uint64_t bytes = (uint64_t)nt * nc * c->n_pairs * 8u;
+        if (bytes <= (32ull << 20) && tiled_blocks(c->n_pairs, false, 1, g.cpb, nc, nt) > 1024u) {
+            g.tpb = 2;
+            g.cpb = 16u;
+            g.wpc = 0;
+        }
     }
-    g.cpb = 12u;
-    g.wpc = 6;
-    const uint32_t tiles = (c->n_pairs + 127u) / 128u;
-    if (tiles >= 2048u) {
-        g.cpb = 10u;
-        g.wpc = 0;
-    }
-    const uint64_t bytes = (uint64_t)nt * nc * c->n_pairs * 8u;
-    if (bytes <= (32ull << 20) && tiled_blocks(c->n_pairs, false, 1, g.cpb, nc, nt) > 1024u) {
-        g.tpb = 2;
-        g.cpb = 16u;
-        g.wpc = 0;
+    // Large launches take the terms-table variant (no per-workgroup set-up, 30-50 VGPRs): its walks are
+    // shorter still -- fp32 2 stores per wave (8 channels), at most 6 workgroups per CU; fp16 64 channels,
+    // 32 with the b16 arithmetic form (profiles/r02_autotune.md, profiles/r02_fp16.md)
+    if (want_terms_table(c, out16, g, nc, nt)) {
+        g.tpb = 1;
+        if (out16) {
+            g.cpb = half ? 32u : 64u;
+            g.wpc = half ? 6 : 0;
+        } else {
+            g.cpb = 8u;
+            g.wpc = 6;
+        }
     }
     return g;
 }
@@ -531,7 +556,6 @@ bf_geom pick_geometry(const dcs_bf_context *c, bool out16, uint32_t nc, uint32_t
     }
     if (c->tune.tiles_per_block) g.tpb = c->tune.tiles_per_block;
     if (c->tune.chan_per_block) g.cpb = (uint32_t)c->tune.chan_per_block;
-    if (c->tune.nontemporal >= 0) g.ntstore = c->tune.nontemporal != 0;
     if (c->tune.wg_per_cu != 0) g.wpc = c->tune.wg_per_cu > 0 ? c->tune.wg_per_cu : 0;
     else if (tiled_blocks(c->n_pairs, out16, g.tpb, g.cpb, nc, nt) <= kResident) g.wpc = 0;
     return g;
@@ -545,16 +569,6 @@ uint32_t lds_pad_for(int k, bool out16, int tpb)
     uint32_t per = (kLds / (uint32_t)k) & ~1023u; // k * per <= 160 KiB < (k + 1) * per for k <= 7
     if (per > 64u * 1024u) per = 64u * 1024u;      // default per-workgroup limit
     return per > stat ? per - stat : 0u;
-}
-
-// Large launches of the tiled form read their pairs' terms from a table written by a pre-pass kernel instead
-// of computing them in every workgroup (bf_kernels.hip, TERMS): form 0 decides by size, form 1 never, form 3 always.
-bool want_terms_table(const dcs_bf_context *c, bool out16, const bf_geom &g, uint32_t nc, uint32_t nt)
-{
-    if (c->tune.probe_nomath || !g.ntstore || nt > kTermsInline) return false;
-    if (c->tune.form == 3) return true;
-    if (c->tune.form != 0) return false;
-    return tiled_blocks(c->n_pairs, out16, g.tpb, g.cpb, nc, nt) > 256u * 8u;
 }
 
 int prepare_tiled(dcs_bf_context *c, bool out16, const float *dt_dev, float dt0, uint32_t nt, uint32_t c0,
@@ -608,6 +622,10 @@ int launch_tiled(dcs_bf_context *c, bool out16, const float *dt_dev, float dt0, 
         ta.pairs_pad = c->pairs_pad;
         ta.nt = nt;
         ta.k = c->k;
+        ta.out = d_out; // this pre-pass also writes the tiles that need the slow path
+        ta.c0 = c0;
+        ta.nc = nc;
+        ta.out16 = out16 ? 1u : 0u;
         const hipError_t e = bf_launch_terms(ta, stream);
         if (e != hipSuccess) return (int)e;
     }
@@ -973,16 +991,17 @@ int dcs_bf_autotune(dcs_bf_context *c, int bitwidth, void *d_out, size_t out_byt
     // fp32: the short walks around the optimum, unlimited and with 5-7 workgroups per CU (fewer waves in flight
     // keep the store stream closer to address order: the best point moves to a slightly longer walk and is
     // ~1 % higher, profiles/r01_store_patterns.md); fp16: VALU-bound, long walks
-    static const int k32[][3] = {{1, 8, -1}, {1, 10, -1}, {1, 11, -1}, {1, 12, -1}, {1, 13, -1}, {1, 14, -1}, {1, 16, -1},
-                                 {1, 20, -1}, {2, 6, -1}, {2, 8, -1}, {2, 12, -1}, {2, 16, -1}, {4, 4, -1}, {4, 8, -1},
-                                 {1, 10, 7}, {1, 11, 7}, {1, 12, 7}, {1, 13, 7}, {1, 14, 7}, {1, 11, 6}, {1, 12, 6}, {1, 13, 6}, {1, 14, 6},
-                                 {1, 14, 5}, {1, 16, 5}};
-    static const int k16[][3] = {{1, 16, -1}, {1, 32, -1}, {1, 64, -1}, {1, 96, -1}, {1, 128, -1}, {1, 192, -1}, {1, 256, -1},
-                                 {1, 128, 7}, {1, 192, 6}, {2, 64, -1}, {4, 32, -1}, {4, 48, -1}};
+    static const int k32[][3] = {{1, 6, -1}, {1, 7, -1}, {1, 8, -1}, {1, 9, -1}, {1, 10, -1}, {1, 11, -1}, {1, 12, -1}, {1, 13, -1},
+                                 {1, 14, -1}, {1, 16, -1}, {1, 7, 7}, {1, 8, 7}, {1, 9, 7}, {1, 10, 7}, {1, 11, 7}, {1, 12, 7},
+                                 {1, 13, 7}, {1, 7, 6}, {1, 8, 6}, {1, 9, 6}, {1, 10, 6}, {1, 11, 6}, {1, 12, 6}, {1, 13, 6},
+                                 {1, 14, 6}, {1, 8, 5}, {1, 14, 5}, {1, 16, 5}, {2, 6, -1}, {2, 8, -1}};
+    static const int k16[][3] = {{1, 16, -1}, {1, 24, -1}, {1, 32, -1}, {1, 48, -1}, {1, 64, -1}, {1, 96, -1}, {1, 128, -1},
+                                 {1, 192, -1}, {1, 256, -1}, {1, 24, 6}, {1, 32, 6}, {1, 48, 6}, {1, 64, 6}, {1, 32, 7},
+                                 {1, 64, 7}, {1, 128, 7}, {2, 32, -1}, {2, 64, -1}};
     const int(*tab)[3] = out16 ? k16 : k32;
     int ncand = out16 ? (int)(sizeof(k16) / sizeof(k16[0])) : (int)(sizeof(k32) / sizeof(k32[0]));
-    cand cands[32];
-    static_assert(sizeof(k32) / sizeof(k32[0]) < 32 && sizeof(k16) / sizeof(k16[0]) < 32, "cands[] too small");
+    cand cands[40];
+    static_assert(sizeof(k32) / sizeof(k32[0]) < 40 && sizeof(k16) / sizeof(k16[0]) < 40, "cands[] too small");
     for (int i = 0; i < ncand; i++) cands[i] = {tab[i][0], tab[i][1], tab[i][2], 1e30};
     // the library's own choice for this shape always takes part (and wins ties, below)
     const bf_geom dflt = shape_default_geometry(c, out16, nc, 1);
@@ -1042,9 +1061,9 @@ int dcs_bf_autotune(dcs_bf_context *c, int bitwidth, void *d_out, size_t out_byt
     // the library default run again, longer (settle, then ~12 ms timed, three interleaved rounds;
     // the mean decides).  A challenger replaces the default only if it is more than 0.7 % faster:
     // below that the ranking is noise, and the default is the geometry the profiles describe.
-    int order[32];
+    int order[40];
     for (int i = 0; i < ncand; i++) order[i] = i;
-    for (int i = 0; i < ncand; i++) // selection sort, ncand <= 32
+    for (int i = 0; i < ncand; i++) // selection sort, ncand <= 40
         for (int j = i + 1; j < ncand; j++)
             if (cands[order[j]].best_ms < cands[order[i]].best_ms) { const int t = order[i]; order[i] = order[j]; order[j] = t; }
     int finalists[5];

@@ -65,6 +65,10 @@ struct bf_terms_args {
     uint32_t n_pairs, pairs_pad, nt;
     dcs_bf_consts k;
     float dt_inline[8];
+    // slow-path duty (tiled form's terms-table variant; nullptr otherwise): the output tensor
+    // [nt][nc][n_pairs] of {re,im} and its channel slab, as in bf_tiled_args
+    void *out;
+    uint32_t c0, nc, out16;
 };
 constexpr uint32_t kTermsInline = 8;
 hipError_t bf_launch_terms(const bf_terms_args &a, hipStream_t stream);

@@ -124,7 +124,10 @@ __device__ __forceinline__ uint32_t pack_half2(const float re, const float im)
 //             VALU issue slots per lane (the fp64 chain with its divide, the class bound) against the
 //             6 (fp32) to 48 (fp16) coefficients a lane then produces on a short walk: 12 of the fp32
 //             kernel's 41.6 lane-operations per coefficient.  Large launches take this variant.
-template <bool OUT16, int TPB, bool NT, bool ALIGNED, bool NOMATH, int TAG = 0, bool INL = false, bool TERMS = false>
+//   HALF    : b16 output from the binary16-sized arithmetic (dcs_sincos_half2; math_mode bit 2) -- its own
+//             instantiation, so that the fp32 sincos path costs it no registers (60 instead of 84 VGPRs: 8
+//             instead of 5 waves per SIMD)
+template <bool OUT16, int TPB, bool NT, bool ALIGNED, bool NOMATH, int TAG = 0, bool INL = false, bool TERMS = false, bool HALF = false>
 __global__ void __launch_bounds__(kBlock) bf_tiled_kernel(const std::conditional_t<INL, bf_tiled_args_inl, bf_tiled_args> args)
 {
     const bf_tiled_args &a = [&]() -> const bf_tiled_args & {
@@ -169,8 +172,9 @@ __global__ void __launch_bounds__(kBlock) bf_tiled_kernel(const std::conditional
                 if (wave_p0 + 64u * (uint32_t)j < a.pairs_pad) cls = max(cls, fl[j]);
         }
         cls = __builtin_amdgcn_readfirstlane(cls);
-        wave_slow = cls == DCS_CLASS_SLOW;
+        wave_slow = false;
         wave_low = cls == DCS_CLASS_FAST_LOW;
+        if (cls == DCS_CLASS_SLOW) return; // bf_terms_kernel has written these tiles itself (slow path)
         if (p0 >= a.n_pairs) return; // pairs_pad >= n_pairs: every load below is inside the table
         const floatx4 *tp = reinterpret_cast<const floatx4 *>(a.terms + 2u * ((uint64_t)t * a.pairs_pad + p0));
 #pragma unroll
@@ -270,10 +274,9 @@ __global__ void __launch_bounds__(kBlock) bf_tiled_kernel(const std::conditional
         return;
     }
 
-    bool half_math = false;
-    if constexpr (OUT16) half_math = a.k.uHalfMath != 0u && !wave_slow;
-    if (half_math) {
-        if constexpr (OUT16) {
+    static_assert(!HALF || OUT16, "the binary16-sized arithmetic is for b16 output");
+    if (HALF && !wave_slow) {
+        if constexpr (HALF) {
             // b16 output, no pair of the wave in the slow class (every |fRotation| < 32000), opted in (math_mode
             // bit 2): the binary16-sized sincos (bf_math.h: dcs_sincos_half2), which yields the packed (re, im) word
             auto walk = [&](auto div3) {
@@ -299,7 +302,7 @@ __global__ void __launch_bounds__(kBlock) bf_tiled_kernel(const std::conditional
             else
                 walk(std::false_type{});
         }
-    } else if (!wave_slow) {
+    } else if (!HALF && !wave_slow) {
         dispatch_fast(a.k.uDiv3Exact != 0u, wave_low, [&](auto div3, auto lowdeg) {
 #pragma unroll 2
             for (uint32_t c = cbeg + row; c < cend; c += ROWS) {
@@ -315,7 +318,7 @@ __global__ void __launch_bounds__(kBlock) bf_tiled_kernel(const std::conditional
                 dst += step;
             }
         });
-    } else {
+    } else if constexpr (!TERMS) {
         for (uint32_t c = cbeg + row; c < cend; c += ROWS) {
             const float fChan = (float)(a.c0 + c);
             float re[PPL], im[PPL];
@@ -457,6 +460,13 @@ __global__ void __launch_bounds__(NW * 64) bf_rows_kernel(const bf_rows_args a)
 // terms[t][p] = {fRateTerm, fPhase0}; flags[t][p/64] = the highest dcs_pair_class of
 // those 64 pairs.  p runs to pairs_pad (a multiple of 256);
 // pairs past n_pairs get zeros.  One lane per (t, p); 64 lanes = one flag word.
+//
+// With a.out set (the tiled form's terms-table variant) this kernel also OWNS the slow path: a workgroup
+// that holds a slow-class pair (|fRotation| may reach 32000, or a rate term outside the constant divide's
+// range) writes all channels of its 256 pairs itself -- IEEE divide, fp64 sincos, one pair per lane -- and
+// marks its four flag words slow, so that the main kernel skips those tiles and carries no fp64 sincos at
+// all (its register count falls from 70-84 to 30-51: 8 waves per SIMD instead of 5-6).  Such inputs are
+// pathological (a delay rate 10^3 beyond the reference's); their tiles take milliseconds here.
 __global__ void __launch_bounds__(kBlock) bf_terms_kernel(const bf_terms_args a)
 {
     const uint32_t p = blockIdx.x * kBlock + threadIdx.x; // < pairs_pad (grid exact)
@@ -473,10 +483,28 @@ __global__ void __launch_bounds__(kBlock) bf_terms_kernel(const bf_terms_args a)
         dcs_pair_terms(d, dt, a.k.dHalfChannels, a.k.dDenominator, &fRate, &fPhase0);
     }
     const uint32_t cls = dcs_pair_class(fRate, fPhase0, a.k.fRotBoundScale, a.k.fLowDegLimit);
-    const uint32_t wave_cls = __builtin_amdgcn_ballot_w64(cls == DCS_CLASS_SLOW) != 0ull
-                                  ? DCS_CLASS_SLOW
-                                  : (__builtin_amdgcn_ballot_w64(cls == DCS_CLASS_FAST_HIGH) != 0ull ? DCS_CLASS_FAST_HIGH
-                                                                                                    : DCS_CLASS_FAST_LOW);
+    uint32_t wave_cls = __builtin_amdgcn_ballot_w64(cls == DCS_CLASS_SLOW) != 0ull
+                            ? DCS_CLASS_SLOW
+                            : (__builtin_amdgcn_ballot_w64(cls == DCS_CLASS_FAST_HIGH) != 0ull ? DCS_CLASS_FAST_HIGH
+                                                                                              : DCS_CLASS_FAST_LOW);
+    if (a.out != nullptr) {
+        if (__syncthreads_or((int)(cls == DCS_CLASS_SLOW))) { // workgroup-uniform
+            wave_cls = DCS_CLASS_SLOW;
+            if (p < a.n_pairs) {
+                const uint64_t eb = a.out16 ? 4u : 8u;
+                char *dst = reinterpret_cast<char *>(a.out) + ((uint64_t)t * a.nc * a.n_pairs + p) * eb;
+                for (uint32_t c = 0; c < a.nc; c++) {
+                    float re, im;
+                    coeff_slow(fRate, fPhase0, (float)(a.c0 + c), a.k.fDenominator, re, im);
+                    if (a.out16)
+                        *reinterpret_cast<uint32_t *>(dst) = pack_half2(re, im);
+                    else
+                        *reinterpret_cast<floatx2 *>(dst) = floatx2{re, im};
+                    dst += (uint64_t)a.n_pairs * eb;
+                }
+            }
+        }
+    }
     *reinterpret_cast<floatx2 *>(a.terms + 2u * ((uint64_t)t * a.pairs_pad + p)) = floatx2{fRate, fPhase0};
     if ((threadIdx.x & 63u) == 0u) a.flags[(uint64_t)t * (a.pairs_pad / 64u) + p / 64u] = wave_cls;
 }
@@ -698,42 +726,58 @@ __global__ void __launch_bounds__(kBlock) bf_gather_beams_kernel(dcs_delay_vals 
     *reinterpret_cast<floatx4 *>(&local[i]) = v;
 }
 
-template <bool OUT16, int TPB, bool NT, bool ALIGNED>
-const void *tiled_fn_nm(bool nomath, bool tuner, bool inl, bool terms)
+// Which instantiations exist: {plain, tuner-tagged, inline-dt, terms-table, terms-table tuner-tagged} x
+// {fp32-sincos arithmetic, binary16-sized arithmetic (b16 output only)}; the terms-table and the binary16 forms
+// with nontemporal stores only (the default policy); the store-only skeleton in the probes build only.
+template <bool OUT16, int TPB, bool NT, bool ALIGNED, bool HALF>
+const void *tiled_fn_h(bool nomath, bool tuner, bool inl, bool terms)
 {
-    if (terms) { // the terms-table variant exists with nontemporal stores only (the default policy)
+    if (terms) {
         if constexpr (NT) {
             if (inl || nomath) return nullptr;
-            return tuner ? reinterpret_cast<const void *>(&bf_tiled_kernel<OUT16, TPB, NT, ALIGNED, false, 1, false, true>)
-                         : reinterpret_cast<const void *>(&bf_tiled_kernel<OUT16, TPB, NT, ALIGNED, false, 0, false, true>);
+            return tuner ? reinterpret_cast<const void *>(&bf_tiled_kernel<OUT16, TPB, NT, ALIGNED, false, 1, false, true, HALF>)
+                         : reinterpret_cast<const void *>(&bf_tiled_kernel<OUT16, TPB, NT, ALIGNED, false, 0, false, true, HALF>);
         } else {
             return nullptr;
         }
     }
-    if (inl) return (nomath || tuner) ? nullptr : reinterpret_cast<const void *>(&bf_tiled_kernel<OUT16, TPB, NT, ALIGNED, false, 0, true>);
-    if (tuner) return reinterpret_cast<const void *>(&bf_tiled_kernel<OUT16, TPB, NT, ALIGNED, false, 1>);
+    if (inl) return (nomath || tuner) ? nullptr : reinterpret_cast<const void *>(&bf_tiled_kernel<OUT16, TPB, NT, ALIGNED, false, 0, true, false, HALF>);
+    if (tuner) return reinterpret_cast<const void *>(&bf_tiled_kernel<OUT16, TPB, NT, ALIGNED, false, 1, false, false, HALF>);
+    if constexpr (!HALF) {
 #ifdef DCS_PROBES
-    if (nomath) return reinterpret_cast<const void *>(&bf_tiled_kernel<OUT16, TPB, NT, ALIGNED, true>);
-#else
-    if (nomath) return nullptr; // the store-only skeleton exists in the probes build only
+        if (nomath) return reinterpret_cast<const void *>(&bf_tiled_kernel<OUT16, TPB, NT, ALIGNED, true>);
 #endif
-    return reinterpret_cast<const void *>(&bf_tiled_kernel<OUT16, TPB, NT, ALIGNED, false>);
+    }
+    if (nomath) return nullptr; // the store-only skeleton exists in the probes build only
+    return reinterpret_cast<const void *>(&bf_tiled_kernel<OUT16, TPB, NT, ALIGNED, false, 0, false, false, HALF>);
+}
+
+template <bool OUT16, int TPB, bool NT, bool ALIGNED>
+const void *tiled_fn_nm(bool nomath, bool tuner, bool inl, bool terms, bool half)
+{
+    if (half) {
+        if constexpr (OUT16 && NT)
+            return tiled_fn_h<OUT16, TPB, NT, ALIGNED, true>(nomath, tuner, inl, terms);
+        else
+            return nullptr;
+    }
+    return tiled_fn_h<OUT16, TPB, NT, ALIGNED, false>(nomath, tuner, inl, terms);
 }
 
 template <bool OUT16, int TPB>
-const void *tiled_fn_t(bool nt, bool aligned, bool nomath, bool tuner, bool inl, bool terms)
+const void *tiled_fn_t(bool nt, bool aligned, bool nomath, bool tuner, bool inl, bool terms, bool half)
 {
-    if (nt) return aligned ? tiled_fn_nm<OUT16, TPB, true, true>(nomath, tuner, inl, terms) : tiled_fn_nm<OUT16, TPB, true, false>(nomath, tuner, inl, terms);
-    return aligned ? tiled_fn_nm<OUT16, TPB, false, true>(nomath, tuner, inl, terms) : tiled_fn_nm<OUT16, TPB, false, false>(nomath, tuner, inl, terms);
+    if (nt) return aligned ? tiled_fn_nm<OUT16, TPB, true, true>(nomath, tuner, inl, terms, half) : tiled_fn_nm<OUT16, TPB, true, false>(nomath, tuner, inl, terms, half);
+    return aligned ? tiled_fn_nm<OUT16, TPB, false, true>(nomath, tuner, inl, terms, half) : tiled_fn_nm<OUT16, TPB, false, false>(nomath, tuner, inl, terms, half);
 }
 
 template <bool OUT16>
-const void *tiled_fn_o(int tpb, bool nt, bool aligned, bool nomath, bool tuner, bool inl, bool terms)
+const void *tiled_fn_o(int tpb, bool nt, bool aligned, bool nomath, bool tuner, bool inl, bool terms, bool half)
 {
     switch (tpb) {
-    case 1: return tiled_fn_t<OUT16, 1>(nt, aligned, nomath, tuner, inl, terms);
-    case 2: return tiled_fn_t<OUT16, 2>(nt, aligned, nomath, tuner, inl, terms);
-    case 4: return tiled_fn_t<OUT16, 4>(nt, aligned, nomath, tuner, inl, terms);
+    case 1: return tiled_fn_t<OUT16, 1>(nt, aligned, nomath, tuner, inl, terms, half);
+    case 2: return tiled_fn_t<OUT16, 2>(nt, aligned, nomath, tuner, inl, terms, half);
+    case 4: return tiled_fn_t<OUT16, 4>(nt, aligned, nomath, tuner, inl, terms, half);
     default: return nullptr;
     }
 }
@@ -764,8 +808,9 @@ hipError_t bf_prepare_tiled(const bf_tiled_args &a_in, const float *dt_inline, b
     if (inl) std::memcpy(out->args.dt_inline, dt_inline, (size_t)a.nt * sizeof(float));
     if (blocks % 8u) a.xcd_remap = 0; // the renumbering is a bijection only then
     const bool aligned = (a.n_pairs % ppl) == 0 && (reinterpret_cast<uintptr_t>(a.out) % 16u) == 0;
-    const void *fn = out16 ? tiled_fn_o<true>(tiles_per_block, nontemporal, aligned, nomath, tuner, inl, terms)
-                           : tiled_fn_o<false>(tiles_per_block, nontemporal, aligned, nomath, tuner, inl, terms);
+    const bool half = out16 && a.k.uHalfMath != 0u;
+    const void *fn = out16 ? tiled_fn_o<true>(tiles_per_block, nontemporal, aligned, nomath, tuner, inl, terms, half)
+                           : tiled_fn_o<false>(tiles_per_block, nontemporal, aligned, nomath, tuner, inl, terms, false);
     if (!fn) return hipErrorInvalidValue;
     out->func = fn;
     out->grid = dim3((uint32_t)blocks);

@@ -110,7 +110,7 @@ def cmd_geometry(args):
             cpbs = (4, 6, 8, 10, 11, 12, 13, 14, 16, 20, 24, 32) if args.bits == 32 else (16, 32, 64, 96, 128, 192, 256)
             for tpb, wpc in ((1, -1), (1, 7), (1, 6), (1, 5), (2, -1), (4, -1)):
                 for cpb in cpbs:
-                    g.set_tuning(form=1, tiles_per_block=tpb, chan_per_block=cpb, nontemporal=1, wg_per_cu=wpc)
+                    g.set_tuning(form=args.form, tiles_per_block=tpb, chan_per_block=cpb, nontemporal=1, wg_per_cu=wpc)
                     ms = per_launch_ms(run, settle_ms=20.0, timed_ms=8.0)
                     table.append((ms, tpb, cpb, wpc))
                     if ms < best[0]:
@@ -119,7 +119,7 @@ def cmd_geometry(args):
             top = sorted(table)[:5]
             best = (1e9, None)
             for _, tpb, cpb, wpc in top:
-                g.set_tuning(form=1, tiles_per_block=tpb, chan_per_block=cpb, nontemporal=1, wg_per_cu=wpc)
+                g.set_tuning(form=args.form, tiles_per_block=tpb, chan_per_block=cpb, nontemporal=1, wg_per_cu=wpc)
                 ms = min(per_launch_ms(run) for _ in range(2))
                 if ms < best[0]:
                     best = (ms, (tpb, cpb, wpc))
@@ -175,14 +175,15 @@ def cmd_refshape(args):
 def cmd_fp16(args):
     bp, g, _, _, buf = make(SHAPES["cfg3"], 32)
     n = bp.coeffs_per_time_step()
-    nb16 = g.output_bytes(0, 1)
+    bw = 1 if args.bits == 32 else 0
+    nb16 = g.output_bytes(bw, 1)
     res = []
     for mode in [int(m) for m in args.modes.split(",")]:
         for tpb in [int(c) for c in args.tpb.split(",")]:
             for wpc in [int(c) for c in args.wpc.split(",")]:
                 for cpb in [int(c) for c in args.cpb.split(",")]:
-                    g.set_tuning(form=1, tiles_per_block=tpb, chan_per_block=cpb, nontemporal=1, math_mode=mode, wg_per_cu=wpc)
-                    ms = min(per_launch_ms(lambda: g.generate(buf, nb16, t0=1, nt=1, bitwidth=0)) for _ in range(2))
+                    g.set_tuning(form=args.form, tiles_per_block=tpb, chan_per_block=cpb, nontemporal=1, math_mode=mode, wg_per_cu=wpc)
+                    ms = min(per_launch_ms(lambda: g.generate(buf, nb16, t0=1, nt=1, bitwidth=bw)) for _ in range(2))
                     res.append((ms, mode, tpb, wpc, cpb))
                     print(f"fp16 math_mode={mode} tpb={tpb} cpb={cpb} wpc={wpc}: {ms:.4f} ms -> {n / ms / 1e6:.1f} Gcoeff/s = {nb16 / ms / 1e9:.2f} TB/s "
                           f"({nb16 / ms / 1e9 / 8 * 100:.1f} % of 8 TB/s)", flush=True)
@@ -362,6 +363,7 @@ def main():
     p.add_argument("--shapes", default="cfg2,mid,cfg3,cfg4,narrow")
     p.add_argument("--bits", type=int, default=32, choices=[16, 32])
     p.add_argument("--sweep", action="store_true")
+    p.add_argument("--form", type=int, default=0, help="form of the sweep's explicit geometries (0 = library's choice, 1 / 3)")
     p.add_argument("--verbose", action="store_true")
     p = sub.add_parser("refshape")
     p.add_argument("--sweep", action="store_true")
@@ -370,6 +372,8 @@ def main():
     p.add_argument("--cpb", default="64,128,256")
     p.add_argument("--wpc", default="-1")
     p.add_argument("--tpb", default="1")
+    p.add_argument("--form", type=int, default=1, help="1 = per-workgroup terms, 3 = terms table, 0 = library's choice")
+    p.add_argument("--bits", type=int, default=16, choices=[16, 32])
     sub.add_parser("fused")
     p = sub.add_parser("stream")
     p.add_argument("--model-step-us", type=float, default=200.0)
