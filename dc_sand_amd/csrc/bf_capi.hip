@@ -499,7 +499,10 @@ bool want_terms_table(const dcs_bf_context *c, bool out16, const bf_geom &g, uin
     if (c->tune.probe_nomath || !g.ntstore || nt > kTermsInline) return false;
     if (c->tune.form == 3) return true;
     if (c->tune.form != 0) return false;
-    return tiled_blocks(c->n_pairs, out16, g.tpb, g.cpb, nc, nt) > 256u * 8u;
+    // the pre-pass is one more kernel (~2 us) and kernel boundary (~1.5 us) per call and buys 2-4 % of the main
+    // kernel's time: worth it from ~1 GiB of output per launch (64 x 64 x 4096, 128 MiB in 21 us, lost 8 % to it)
+    const uint64_t bytes = (uint64_t)nt * nc * c->n_pairs * (out16 ? 4u : 8u);
+    return bytes >= (1ull << 30) && tiled_blocks(c->n_pairs, out16, g.tpb, g.cpb, nc, nt) > 256u * 8u;
 }
 
 bf_geom shape_default_geometry(const dcs_bf_context *c, bool out16, uint32_t nc, uint32_t nt)
@@ -540,6 +543,13 @@ bf_geom shape_default_geometry(const dcs_bf_context *c, bool out16, uint32_t nc,
             g.cpb = 8u;
             g.wpc = 6;
         }
+    }
+    // rows of at most 4 tiles (<= 4 KiB): consecutive rows are nearly adjacent in memory, and a workgroup does
+    // better writing 16 of them, two tiles wide (64 KiB contiguous), than a short walk
+    if (!out16 && (c->n_pairs + 127u) / 128u <= 4u) {
+        g.tpb = c->n_pairs > 128u ? 2 : 1;
+        g.cpb = 16u;
+        g.wpc = 0;
     }
     return g;
 }
@@ -971,6 +981,11 @@ int dcs_bf_autotune(dcs_bf_context *c, int bitwidth, void *d_out, size_t out_byt
     if (nc64 > (uint64_t)c->p.nr_channels) nc64 = (uint64_t)c->p.nr_channels;
     if (nc64 == 0) return DCS_ERR_INVALID_ARGUMENT;
     const uint32_t nc = (uint32_t)nc64;
+    // a buffer that holds several whole time steps is tuned as one launch of that many (up to 256, which
+    // travel in the kernel arguments): the reference's own tensor is 256 small time steps, not one
+    uint64_t nt64 = out_bytes / (row * nc);
+    if (nt64 > kDtInline) nt64 = kDtInline;
+    const uint32_t nt_tune = nc == (uint32_t)c->p.nr_channels && nt64 > 1 ? (uint32_t)nt64 : 1u;
     hipStream_t s = as_stream(stream);
     dcs_bf_context::tuned_geom &slot = c->tuned[out16 ? 1 : 0];
 
@@ -1004,7 +1019,7 @@ int dcs_bf_autotune(dcs_bf_context *c, int bitwidth, void *d_out, size_t out_byt
     static_assert(sizeof(k32) / sizeof(k32[0]) < 40 && sizeof(k16) / sizeof(k16[0]) < 40, "cands[] too small");
     for (int i = 0; i < ncand; i++) cands[i] = {tab[i][0], tab[i][1], tab[i][2], 1e30};
     // the library's own choice for this shape always takes part (and wins ties, below)
-    const bf_geom dflt = shape_default_geometry(c, out16, nc, 1);
+    const bf_geom dflt = shape_default_geometry(c, out16, nc, nt_tune);
     int i_default = -1;
     for (int i = 0; i < ncand; i++)
         if (cands[i].tpb == dflt.tpb && cands[i].cpb == (int)dflt.cpb && (cands[i].wpc > 0 ? cands[i].wpc : 0) == dflt.wpc) i_default = i;
@@ -1013,6 +1028,16 @@ int dcs_bf_autotune(dcs_bf_context *c, int bitwidth, void *d_out, size_t out_byt
         cands[ncand++] = {dflt.tpb, (int)dflt.cpb, dflt.wpc > 0 ? dflt.wpc : -1, 1e30};
     }
 
+    if (tiled_blocks(c->n_pairs, out16, dflt.tpb, dflt.cpb, nc, nt_tune) <= 256u * 8u) {
+        // every workgroup of this launch is resident at once: launch-bound, nothing to tune -- the tuned
+        // geometry only ever applies to launches that oversubscribe the chip (pick_geometry)
+        slot.valid = true;
+        slot.tpb = dflt.tpb;
+        slot.cpb = (int32_t)dflt.cpb;
+        slot.wpc = dflt.wpc > 0 ? dflt.wpc : -1;
+        report();
+        return DCS_OK;
+    }
     const dcs_bf_tuning saved = c->tune;
     c->tuning_now = true;
     auto use = [&](const cand &k) {
@@ -1031,14 +1056,14 @@ int dcs_bf_autotune(dcs_bf_context *c, int bitwidth, void *d_out, size_t out_byt
     // interleaved rounds; a candidate's score is its better round.
     auto time_launches = [&](int n, float *ms) -> int {
         int r = (int)hipEventRecord(e0, s);
-        for (int k = 0; k < n && r == 0; k++) r = dcs_bf_generate_slab(c, bitwidth, 1, 1, 0, nc, d_out, out_bytes, stream);
+        for (int k = 0; k < n && r == 0; k++) r = dcs_bf_generate_slab(c, bitwidth, 1, nt_tune, 0, nc, d_out, out_bytes, stream);
         if (r == 0) r = (int)hipEventRecord(e1, s);
         if (r == 0) r = (int)hipEventSynchronize(e1);
         if (r == 0) r = (int)hipEventElapsedTime(ms, e0, e1);
         return r;
     };
     float cal_ms = 0.0f;
-    for (int i = 0; i < 10 && st == 0; i++) st = dcs_bf_generate_slab(c, bitwidth, 1, 1, 0, nc, d_out, out_bytes, stream);
+    for (int i = 0; i < 10 && st == 0; i++) st = dcs_bf_generate_slab(c, bitwidth, 1, nt_tune, 0, nc, d_out, out_bytes, stream);
     if (st == 0) st = time_launches(4, &cal_ms);
     const double one = cal_ms > 0.0f ? cal_ms / 4.0 : 1.0; // ms per launch at the current geometry
     const int n_settle = (int)std::fmin(400.0, std::fmax(8.0, std::ceil(20.0 / one)));
@@ -1051,7 +1076,7 @@ int dcs_bf_autotune(dcs_bf_context *c, int bitwidth, void *d_out, size_t out_byt
             // slows by ~1 % over the first seconds of sustained load, so a short tuner is a better one)
             if (rnd == 1 && i != i_default && cands[i].best_ms > 1.04 * best_so_far) continue;
             use(cands[i]);
-            for (int k = 0; k < n_settle && st == 0; k++) st = dcs_bf_generate_slab(c, bitwidth, 1, 1, 0, nc, d_out, out_bytes, stream);
+            for (int k = 0; k < n_settle && st == 0; k++) st = dcs_bf_generate_slab(c, bitwidth, 1, nt_tune, 0, nc, d_out, out_bytes, stream);
             float ms = 0.0f;
             if (st == 0) st = time_launches(n_timed, &ms);
             if (st == 0 && ms / n_timed < cands[i].best_ms) cands[i].best_ms = ms / n_timed;
@@ -1076,7 +1101,7 @@ int dcs_bf_autotune(dcs_bf_context *c, int bitwidth, void *d_out, size_t out_byt
     for (int rnd = 0; rnd < 3 && st == 0; rnd++) {
         for (int f = 0; f < nfinal && st == 0; f++) {
             use(cands[finalists[f]]);
-            for (int i = 0; i < n_settle && st == 0; i++) st = dcs_bf_generate_slab(c, bitwidth, 1, 1, 0, nc, d_out, out_bytes, stream);
+            for (int i = 0; i < n_settle && st == 0; i++) st = dcs_bf_generate_slab(c, bitwidth, 1, nt_tune, 0, nc, d_out, out_bytes, stream);
             float ms = 0.0f;
             if (st == 0) st = time_launches(n_final, &ms);
             final_ms[f] += ms / n_final;
@@ -1091,7 +1116,7 @@ int dcs_bf_autotune(dcs_bf_context *c, int bitwidth, void *d_out, size_t out_byt
     if (st == 0) {
         // leave the device settled on the chosen geometry (still under the tuner's kernel symbols)
         use(cands[best]);
-        for (int k = 0; k < n_settle && st == 0; k++) st = dcs_bf_generate_slab(c, bitwidth, 1, 1, 0, nc, d_out, out_bytes, stream);
+        for (int k = 0; k < n_settle && st == 0; k++) st = dcs_bf_generate_slab(c, bitwidth, 1, nt_tune, 0, nc, d_out, out_bytes, stream);
     }
     c->tune = saved;
     c->tuning_now = false;

@@ -741,7 +741,8 @@ const void *tiled_fn_h(bool nomath, bool tuner, bool inl, bool terms)
             return nullptr;
         }
     }
-    if (inl) return (nomath || tuner) ? nullptr : reinterpret_cast<const void *>(&bf_tiled_kernel<OUT16, TPB, NT, ALIGNED, false, 0, true, false, HALF>);
+    // (inline-dt launches have no tuner-tagged twin: the tuner's multi-time-step trials run under the production symbol)
+    if (inl) return nomath ? nullptr : reinterpret_cast<const void *>(&bf_tiled_kernel<OUT16, TPB, NT, ALIGNED, false, 0, true, false, HALF>);
     if (tuner) return reinterpret_cast<const void *>(&bf_tiled_kernel<OUT16, TPB, NT, ALIGNED, false, 1, false, false, HALF>);
     if constexpr (!HALF) {
 #ifdef DCS_PROBES

@@ -174,8 +174,12 @@ class SteeringCoefficientGenerator:
                    rows_same_tile: int = -1, probe_pace: int = 0, math_mode: int = 0, wg_per_cu: int = 0) -> None:
         """``struct dcs_bf_tuning``; ``set_tuning()`` restores the defaults.  ``probe_nomath`` / ``probe_pace`` are
         honoured only by the probes build of the library (include/dcs_probes.h); the product library refuses them."""
-        t = (ctypes.c_int32 * 12)(form, nontemporal, chan_per_block, tiles_per_block, waves_per_block, rows_per_wave,
-                                  xcd_remap, 1 if probe_nomath else 0, rows_same_tile, probe_pace, math_mode, wg_per_cu)
+        vals = (form, nontemporal, chan_per_block, tiles_per_block, waves_per_block, rows_per_wave,
+                xcd_remap, 1 if probe_nomath else 0, rows_same_tile, probe_pace, math_mode, wg_per_cu)
+        if vals == (0, -1, 0, 0, 0, 0, -1, 0, -1, 0, 0, 0):  # all defaults: NULL, which also forgets dcs_bf_autotune's result
+            check(_lib.lib().dcs_bf_set_tuning(c_void_p(self._h), c_void_p(None)), "dcs_bf_set_tuning")
+            return
+        t = (ctypes.c_int32 * 12)(*vals)
         check(_lib.lib().dcs_bf_set_tuning(c_void_p(self._h), ctypes.cast(t, c_void_p)), "dcs_bf_set_tuning")
 
     TUNING_FIELDS = ("form", "nontemporal", "chan_per_block", "tiles_per_block", "waves_per_block", "rows_per_wave",

@@ -233,7 +233,7 @@ int dcs_bf_generate_and_beamform_dt(dcs_bf_context *ctx, const float *dt, uint32
  *           small table a pre-pass kernel writes just before (form 3; at most 8 time steps per launch,
  *           nontemporal stores): the pre-pass costs ~3 us and takes ~12 of 41 VALU operations per fp32
  *           coefficient out of the main kernel.  form 0 (default) picks by size: the table for launches
- *           that oversubscribe the chip, per-workgroup terms for small ones (and always inside
+ *           of >= 1 GiB of output, per-workgroup terms for smaller ones (and always inside
  *           dcs_bf_stream_* graphs, which hold one kernel node);
  *   form 2 "rows":  the terms table for any number of time steps, then short waves
  *           (waves_per_block adjacent 1-KiB tiles x rows_per_wave channel rows)
