@@ -15,6 +15,10 @@ Rank 0 prints ONE JSON line.  ``roofline`` prices the dominant kernel against
 the 8 TB/s HBM peak with its ALGORITHMIC bytes (8 B per coefficient written);
 ``cpu_baseline`` times the CPU oracle (the restated reference verifier, one
 thread like the reference) on a bounded channel slab of the same workload.
+``also_measured`` (N = 1) carries what the headline's 50-step burst does not show: the SUSTAINED rate over >= 5 s of
+back-to-back steps, BASELINE configs[4] (streaming at a 200 us cadence: full-tensor period and the largest slab that
+keeps the cadence, model time advancing 200 us per tick), the fp16 output modes and the fused beamformer.  At N > 1
+``per_rank`` holds every rank's own kernel time and launch geometry, and ``rccl_world_size`` the communicator's size.
 The oracle is loaded only in that cpu_baseline leg (where it is also used to
 spot-check the last generated step), never inside the timed GPU region; with
 --no-cpu-baseline bench.py does not touch oracle/ at all.
@@ -55,6 +59,7 @@ def parse():
                          "untimed set-up (its trial launches run under separate kernel symbols, template TAG = 1, so a "
                          "rocprofv3 --stats of this command still averages only the production launches)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline sample time")
+    ap.add_argument("--sustain-seconds", type=float, default=5.0, help="length of the sustained-rate side measurement (N = 1)")
     # rehearsal of the N > 1 control flow on a box with fewer GPUs than ranks (never a result):
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="nccl = RCCL over xGMI (the product path)")
     ap.add_argument("--shared-device", action="store_true", help="rehearsal: every rank uses GPU 0")
@@ -104,10 +109,15 @@ def cpu_baseline(bp, table, seconds: float) -> dict:
     return out
 
 
-def extras(gen, bp, out, out_bytes, sh, device) -> dict:
-    """Side measurements after the timed region (N = 1): the fp16 output mode of the same
-    workload and the fused coefficient-generation + beamforming kernel
-    (f1) on a 64 x 64 x 4096 x 64 problem.  Same HIP-event method, 20 launches each."""
+def extras(gen, bp, out, out_bytes, sh, device, sustain_seconds: float) -> dict:
+    """Side measurements after the timed region (N = 1), same HIP-event method:
+    * ``sustained``: >= 5 s of back-to-back steps of the headline workload at the geometry the headline ran with
+      (the chip's write rate sags ~1-3 % over the first seconds of load; a real-time generator lives there);
+    * ``streaming_cfg5``: BASELINE configs[4] -- hipGraph replay, one time step per tick, model time advancing
+      200 us per tick (dcs_bf_stream_tick_dt): the full tensor's update period (it cannot meet 200 us: 16 GiB
+      need >= 2.15 ms at the 8 TB/s peak) and the largest channel slab whose period stays <= 200 us;
+    * ``fp16_output``: the b16 output mode (SURVEY 8 f2), exact-RNE form and the opt-in b16 arithmetic form;
+    * ``fused_generate_and_beamform`` (f1) on a 64 x 64 x 4096 x 64 problem."""
     from dc_sand_amd import BeamformerParameters
     from dc_sand_amd.generator import SteeringCoefficientGenerator, simulate_input
 
@@ -123,11 +133,76 @@ def extras(gen, bp, out, out_bytes, sh, device) -> dict:
         return e1.elapsed_ms_since(e0) / n
 
     res = {}
-    gen.set_tuning()
+    n_coeff = bp.coeffs_per_time_step()
+
+    # -- sustained: batches of 50 launches, the host one batch ahead of the device; per-second rates kept
+    batch, k, total_ms, launches, per_sec = 50, 0, 0.0, 0, []
+    ev = [device.Event().record(sh)]
+    t_end = time.perf_counter() + sustain_seconds
+    sec_ms, sec_n = 0.0, 0
+    while True:
+        for _ in range(batch):
+            gen.generate(out.data_ptr(), out_bytes, t0=1 + (k % 255), nt=1, stream=sh)
+            k += 1
+        ev.append(device.Event().record(sh))
+        if len(ev) >= 3:  # wait for the batch before the one just queued
+            ev[-2].synchronize()
+            ms = ev[-2].elapsed_ms_since(ev[-3])
+            total_ms += ms
+            launches += batch
+            sec_ms += ms
+            sec_n += batch
+            if sec_ms >= 1000.0:
+                per_sec.append(n_coeff * sec_n / sec_ms / 1e6)
+                sec_ms, sec_n = 0.0, 0
+        if time.perf_counter() >= t_end and launches > 0:
+            break
+    ev[-1].synchronize()
+    total_ms += ev[-1].elapsed_ms_since(ev[-2])
+    launches += batch
+    res["sustained"] = {"value": n_coeff * launches / total_ms / 1e6, "unit": "Gcoeff/s", "seconds": total_ms / 1e3, "launches": launches,
+                        "ms_per_step": total_ms / launches, "frac_of_hbm_peak": 8 * n_coeff * launches / total_ms / 1e6 / HBM_PEAK_GBPS,
+                        "per_second": per_sec, "note": "back-to-back steps of the headline workload, same kernel and launch geometry"}
+
+    # -- BASELINE configs[4]: streaming at a 200 us cadence
+    def tick_period_us(nc, ticks=150, warm=15):
+        nbytes = nc * bp.n_pairs * 8
+        st = gen.stream_begin(out.data_ptr(), nbytes, 0, nc, sh)
+        for i in range(warm):
+            st.tick_dt(i * 200e-6)
+        device.stream_synchronize(sh)
+        e0, e1 = device.Event().record(sh), device.Event()
+        t0 = time.perf_counter()
+        for i in range(ticks):
+            st.tick_dt((warm + i) * 200e-6)
+        e1.record(sh)
+        e1.synchronize()
+        wall = (time.perf_counter() - t0) / ticks * 1e6
+        dev = e1.elapsed_ms_since(e0) / ticks * 1e3
+        st.end()
+        return max(dev, wall), nbytes
+
+    full_us, full_bytes = tick_period_us(bp.NR_CHANNELS, ticks=60, warm=6)
+    best = None
+    for nc in (1536, 2048, 2304, 2432, 2560, 2688, 2816):
+        if nc > bp.NR_CHANNELS:
+            break
+        us, nb = tick_period_us(nc)
+        if us <= 200.0:
+            best = {"channels": nc, "bytes_per_tick": nb, "period_us": us, "Mcoeff_per_tick": nc * bp.n_pairs / 1e6, "TBps": nb / us / 1e6}
+    res["streaming_cfg5"] = {"cadence_target_us": 200.0, "model_time_step_us": 200.0, "launch": "hipGraph replay, dcs_bf_stream_tick_dt",
+                             "full_tensor_period_us": full_us, "full_tensor_TBps": full_bytes / full_us / 1e6,
+                             "meets_200us_full_tensor": bool(full_us <= 200.0), "largest_slab_at_200us": best}
+
+    # -- fp16 output, both arithmetic forms (library default geometry for each)
     nb16 = gen.output_bytes(0, 1)
-    ms = timed(lambda: gen.generate(out.data_ptr(), nb16, t0=1, nt=1, bitwidth=0, stream=sh))
-    res["fp16_output"] = {"value": bp.coeffs_per_time_step() / ms / 1e6, "unit": "Gcoeff/s", "ms": ms,
-                          "hbm_GBps": nb16 / ms / 1e6, "bound": "fp32 VALU (4 B written per coefficient)"}
+    for key, mode in (("fp16_output", 0), ("fp16_output_b16_arithmetic", 4)):
+        gen.set_tuning() if mode == 0 else gen.set_tuning(math_mode=mode)
+        ms = timed(lambda: gen.generate(out.data_ptr(), nb16, t0=1, nt=1, bitwidth=0, stream=sh), n=40, warm=20)
+        res[key] = {"value": n_coeff / ms / 1e6, "unit": "Gcoeff/s", "ms": ms, "hbm_GBps": nb16 / ms / 1e6,
+                    "frac_of_hbm_peak": nb16 / ms / 1e6 / HBM_PEAK_GBPS, "math_mode": mode,
+                    "bound": "4 B written per coefficient: fp32 VALU issue (exact-RNE form) / HBM write pattern (b16 form)"}
+    gen.set_tuning()
     A, B, C, nt = 64, 64, 4096, 64
     fp = BeamformerParameters(NR_CHANNELS=C, NR_STATIONS=A, NR_BEAMS=B, NR_SAMPLES_PER_CHANNEL=nt)
     g = SteeringCoefficientGenerator(fp)
@@ -144,16 +219,20 @@ def extras(gen, bp, out, out_bytes, sh, device) -> dict:
 
 
 def pmc_traffic(bytes_algo: int):
-    """HBM bytes (write + corrected read) per launch from the committed rocprofv3 --pmc passes of this
-    same workload (profiles/pmc_write_size.json), or None."""
+    """(HBM bytes per launch, source) from the committed rocprofv3 --pmc passes of this same workload
+    (profiles/pmc_write_size.json: WRITE_SIZE and FETCH_SIZE in separate passes of this command), or (None, None).
+    The counters cannot be read from inside an un-profiled run, so this is that committed measurement, labelled."""
     f = ROOT / "profiles" / "pmc_write_size.json"
     try:
         d = json.loads(f.read_text())
         if int(d.get("algorithmic_bytes_per_launch", -1)) == int(bytes_algo):
-            return float(d["hbm_bytes_per_launch"])
+            src = (f"profiles/pmc_write_size.json: rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE (separate passes) of `bench.py` in {d.get('round', 'r01')}, "
+                   f"kernel {d.get('kernel', '?')[:80]}, launch geometry {d.get('launch_geometry', 'library default')}; every store is a whole 128-B line, "
+                   "so the bytes do not depend on the geometry")
+            return float(d["hbm_bytes_per_launch"]), src
     except Exception:
         pass
-    return None
+    return None, None
 
 
 def main():
@@ -302,6 +381,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t_start
+    elapsed_local = elapsed
     ev_ms = e1.elapsed_ms_since(e0)
 
     if use_dist:
@@ -312,6 +392,19 @@ def main():
     coeffs_per_gpu_step = bp.coeffs_per_time_step()
     total_coeffs = coeffs_per_gpu_step * N * args.steps
     value = total_coeffs / elapsed / 1e9
+
+    # every rank's own numbers (each rank tunes and times independently): a scaling efficiency below 1 can then be
+    # attributed to the slowest GPU, to the collective or to launch skew
+    geom_keys = ("tiles_per_block", "chan_per_block", "nontemporal", "wg_per_cu")
+    mine = {"rank": rank, "kernel_ms": ev_ms / args.steps, "wall_ms_per_step": elapsed_local / args.steps * 1e3,
+            "geometry": ({k: tuning[k] for k in geom_keys} if tuning else "library defaults")}
+    per_rank = [mine]
+    comm_world = 1
+    if use_dist:
+        comm_world = dist.get_world_size()
+        gathered = [None] * comm_world
+        dist.all_gather_object(gathered, mine)
+        per_rank = gathered
 
     def spot_check():
         """First channels of the last generated step of THIS rank's slab vs the oracle
@@ -346,6 +439,7 @@ def main():
             print("per-step ms:", " ".join(f"{x:.3f}" for x in per_step), file=sys.stderr)
         algo_bytes = 8 * coeffs_per_gpu_step
         achieved = algo_bytes / (kern_ms * 1e-3) / 1e9
+        traffic, traffic_source = pmc_traffic(algo_bytes)
         result = {
             "metric": f"Gcoeff/s (complex weights) {args.ant}ant x {args.beams_per_gpu}beam x {args.chan}chan per GPU",
             "value": value,
@@ -364,18 +458,21 @@ def main():
                             f"beam-sharded {args.beams_per_gpu} beams/GPU" + (f", {args.backend} bcast of the delay table each step" if use_dist else ""),
                 "coeffs_per_step": coeffs_per_gpu_step * N,
                 "output_bytes_per_gpu_step": out_bytes,
-                "kernel": "MULTIPLE_CHANNELS_AND_TIMESTAMPS (tiled form)",
+                "kernel": "MULTIPLE_CHANNELS_AND_TIMESTAMPS (tiled form; launches of >= 2 GiB read the pairs' terms from a pre-pass table)",
                 "launch_geometry": ({k: tuning[k] for k in ("tiles_per_block", "chan_per_block", "nontemporal", "wg_per_cu")} if tuning
                                     else "library defaults"),
                 "collective": ("none" if not use_dist else ("RCCL broadcast" if args.backend == "nccl" else "gloo broadcast (REHEARSAL, not a result)")),
             },
+            "per_rank": per_rank,
+            "rccl_world_size": (comm_world if (use_dist and args.backend == "nccl") else None),
             "roofline": {
                 "bound": "hbm",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS,
-                "traffic": pmc_traffic(algo_bytes),
+                "traffic": traffic,
+                "traffic_source": traffic_source,
                 "kernel_ms": kern_ms,
                 **({"kernel_ms_median": float(np.median(per_step)), "kernel_ms_min": float(np.min(per_step)),
                     "kernel_ms_max": float(np.max(per_step))} if per_step_events else {}),
@@ -386,7 +483,7 @@ def main():
         if N == 1 and not args.no_cpu_baseline:
             check = spot_check()  # before anything else rewrites the output buffer
         if N == 1 and not args.no_extras:
-            result["also_measured"] = extras(gen, bp, out, out_bytes, sh, device)
+            result["also_measured"] = extras(gen, bp, out, out_bytes, sh, device, args.sustain_seconds)
         if N == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(bp, np.ascontiguousarray(table_host), args.cpu_seconds)
             result["cpu_baseline"]["gpu_vs_oracle_spot_check"] = {"max_ulp": check[0], "over_1ulp": check[1],

@@ -130,6 +130,12 @@ struct dcs_bf_stream {
     hipGraphExec_t exec;
     hipGraphNode_t node;
     bf_kernel_launch launch;     // the node's kernel, geometry and arguments
+    // slabs of >= 1 GiB take the tiled form's terms-table variant: a second kernel node in front (the pre-pass)
+    bool has_terms;
+    hipGraphNode_t terms_node;
+    bf_terms_args terms_args;
+    const void *terms_func;
+    dim3 terms_grid, terms_block;
     dcs_delay_vals *h_table;     // pinned staging for table updates
     hipEvent_t table_copied;     // h_table may be rewritten after this
     bool table_pending;
@@ -500,9 +506,10 @@ bool want_terms_table(const dcs_bf_context *c, bool out16, const bf_geom &g, uin
     if (c->tune.form == 3) return true;
     if (c->tune.form != 0) return false;
     // the pre-pass is one more kernel (~2 us) and kernel boundary (~1.5 us) per call and buys 2-4 % of the main
-    // kernel's time: worth it from ~1 GiB of output per launch (64 x 64 x 4096, 128 MiB in 21 us, lost 8 % to it)
+    // kernel's time: it breaks even at 1-2 GiB of output per launch (64 x 64 x 4096, 128 MiB in 21 us, lost 8 %
+    // to it; the 1.3 GB slab of a 200 us streaming tick lost 2 %; 64 x 256 x 8192, 1 GiB, was level)
     const uint64_t bytes = (uint64_t)nt * nc * c->n_pairs * (out16 ? 4u : 8u);
-    return bytes >= (1ull << 30) && tiled_blocks(c->n_pairs, out16, g.tpb, g.cpb, nc, nt) > 256u * 8u;
+    return bytes >= (2ull << 30) && tiled_blocks(c->n_pairs, out16, g.tpb, g.cpb, nc, nt) > 256u * 8u;
 }
 
 bf_geom shape_default_geometry(const dcs_bf_context *c, bool out16, uint32_t nc, uint32_t nt)
@@ -613,6 +620,28 @@ int prepare_tiled(dcs_bf_context *c, bool out16, const float *dt_dev, float dt0,
     return st;
 }
 
+// Arguments of the pre-pass kernel of the terms-table variant (it also writes the tiles that need the slow path).
+void fill_terms_table_args(const dcs_bf_context *c, bool out16, float dt0, uint32_t nt, uint32_t c0, uint32_t nc, void *d_out,
+                           const float *dt_host, bf_terms_args *ta)
+{
+    std::memset(ta, 0, sizeof(*ta));
+    ta->delays = c->d_table[c->cur];
+    ta->terms = c->d_tt_terms;
+    ta->flags = c->d_tt_flags;
+    ta->dt_dev = nullptr;
+    ta->dt0 = dt0;
+    ta->dt_inline[0] = dt0;
+    if (nt > 1 && dt_host) std::memcpy(ta->dt_inline, dt_host, (size_t)nt * sizeof(float));
+    ta->n_pairs = c->n_pairs;
+    ta->pairs_pad = c->pairs_pad;
+    ta->nt = nt;
+    ta->k = c->k;
+    ta->out = d_out;
+    ta->c0 = c0;
+    ta->nc = nc;
+    ta->out16 = out16 ? 1u : 0u;
+}
+
 int launch_tiled(dcs_bf_context *c, bool out16, const float *dt_dev, float dt0, uint32_t nt, uint32_t c0,
                  uint32_t nc, void *d_out, hipStream_t stream, const float *dt_host = nullptr)
 {
@@ -620,22 +649,7 @@ int launch_tiled(dcs_bf_context *c, bool out16, const float *dt_dev, float dt0, 
                     want_terms_table(c, out16, pick_geometry(c, out16, nc, nt), nc, nt);
     if (tt) {
         bf_terms_args ta;
-        std::memset(&ta, 0, sizeof(ta));
-        ta.delays = c->d_table[c->cur];
-        ta.terms = c->d_tt_terms;
-        ta.flags = c->d_tt_flags;
-        ta.dt_dev = nullptr;
-        ta.dt0 = dt0;
-        ta.dt_inline[0] = dt0;
-        if (nt > 1) std::memcpy(ta.dt_inline, dt_host, (size_t)nt * sizeof(float));
-        ta.n_pairs = c->n_pairs;
-        ta.pairs_pad = c->pairs_pad;
-        ta.nt = nt;
-        ta.k = c->k;
-        ta.out = d_out; // this pre-pass also writes the tiles that need the slow path
-        ta.c0 = c0;
-        ta.nc = nc;
-        ta.out16 = out16 ? 1u : 0u;
+        fill_terms_table_args(c, out16, dt0, nt, c0, nc, d_out, dt_host, &ta);
         const hipError_t e = bf_launch_terms(ta, stream);
         if (e != hipSuccess) return (int)e;
     }
@@ -1168,8 +1182,14 @@ int dcs_bf_stream_begin(dcs_bf_context *c, int bitwidth, uint32_t c0, uint32_t n
     s->stream = as_stream(stream);
     int st = DCS_OK;
     do {
-        if ((st = prepare_tiled(c, out16, nullptr, 0.0f, 1, c0, nc, d_out, &s->launch)) != 0) break;
+        s->has_terms = want_terms_table(c, out16, pick_geometry(c, out16, nc, 1), nc, 1);
+        if ((st = prepare_tiled(c, out16, nullptr, 0.0f, 1, c0, nc, d_out, &s->launch, nullptr, s->has_terms)) != 0) break;
         if (s->launch.func == nullptr) { st = DCS_ERR_INVALID_ARGUMENT; break; }
+        if (s->has_terms) {
+            fill_terms_table_args(c, out16, 0.0f, 1, c0, nc, d_out, nullptr, &s->terms_args);
+            if ((st = (int)bf_prepare_terms(s->terms_args, &s->terms_func, &s->terms_grid, &s->terms_block)) != 0) break;
+            if (s->terms_func == nullptr) { st = DCS_ERR_INVALID_ARGUMENT; break; }
+        }
         if ((st = (int)hipHostMalloc((void **)&s->h_table, (size_t)c->n_pairs * sizeof(dcs_delay_vals),
                                      hipHostMallocDefault)) != 0) break;
         if ((st = (int)hipEventCreateWithFlags(&s->table_copied, hipEventDisableTiming)) != 0) break;
@@ -1183,7 +1203,19 @@ int dcs_bf_stream_begin(dcs_bf_context *c, int bitwidth, uint32_t c0, uint32_t n
         np.sharedMemBytes = s->launch.shared;
         np.kernelParams = params;
         np.extra = nullptr;
-        if ((st = (int)hipGraphAddKernelNode(&s->node, s->graph, nullptr, 0, &np)) != 0) break;
+        if (s->has_terms) { // pre-pass node first; the generator node depends on it
+            void *tparams[] = {&s->terms_args};
+            hipKernelNodeParams tp;
+            std::memset(&tp, 0, sizeof(tp));
+            tp.func = const_cast<void *>(s->terms_func);
+            tp.gridDim = s->terms_grid;
+            tp.blockDim = s->terms_block;
+            tp.kernelParams = tparams;
+            if ((st = (int)hipGraphAddKernelNode(&s->terms_node, s->graph, nullptr, 0, &tp)) != 0) break;
+            if ((st = (int)hipGraphAddKernelNode(&s->node, s->graph, &s->terms_node, 1, &np)) != 0) break;
+        } else {
+            if ((st = (int)hipGraphAddKernelNode(&s->node, s->graph, nullptr, 0, &np)) != 0) break;
+        }
         if ((st = (int)hipGraphInstantiate(&s->exec, s->graph, nullptr, nullptr, 0)) != 0) break;
     } while (0);
     if (st != 0) {
@@ -1213,6 +1245,19 @@ int dcs_bf_stream_tick_dt(dcs_bf_stream *s, float dt, const dcs_delay_vals *new_
     }
     s->launch.args.a.dt0 = dt;
     s->launch.args.a.delays = c->d_table[c->cur];
+    if (s->has_terms) {
+        s->terms_args.dt0 = dt;
+        s->terms_args.dt_inline[0] = dt;
+        s->terms_args.delays = c->d_table[c->cur];
+        void *tparams[] = {&s->terms_args};
+        hipKernelNodeParams tp;
+        std::memset(&tp, 0, sizeof(tp));
+        tp.func = const_cast<void *>(s->terms_func);
+        tp.gridDim = s->terms_grid;
+        tp.blockDim = s->terms_block;
+        tp.kernelParams = tparams;
+        DCS_TRY(hipGraphExecKernelNodeSetParams(s->exec, s->terms_node, &tp));
+    }
     void *params[] = {&s->launch.args};
     hipKernelNodeParams np;
     std::memset(&np, 0, sizeof(np));

@@ -72,6 +72,8 @@ struct bf_terms_args {
 };
 constexpr uint32_t kTermsInline = 8;
 hipError_t bf_launch_terms(const bf_terms_args &a, hipStream_t stream);
+// the same launch resolved but not enqueued (a hipGraph kernel node is built from it); *func == nullptr: nothing to launch
+hipError_t bf_prepare_terms(const bf_terms_args &a, const void **func, dim3 *grid, dim3 *block);
 
 struct bf_rows_args {
     const float *terms;

@@ -889,14 +889,26 @@ hipError_t launch_rows_o(const bf_rows_args &a, int nw, int rpw, bool nt, bool a
 
 } // namespace
 
-hipError_t bf_launch_terms(const bf_terms_args &a, hipStream_t stream)
+hipError_t bf_prepare_terms(const bf_terms_args &a, const void **func, dim3 *grid, dim3 *block)
 {
+    *func = nullptr;
     if (a.nt == 0 || a.pairs_pad == 0) return hipSuccess;
     if (a.pairs_pad % kBlock || a.nt > 65535u) return hipErrorInvalidValue;
     if (a.dt_dev == nullptr && a.nt > kTermsInline) return hipErrorInvalidValue;
-    const dim3 grid(a.pairs_pad / kBlock, a.nt);
-    hipLaunchKernelGGL(bf_terms_kernel, grid, dim3(kBlock), 0, stream, a);
-    return hipGetLastError();
+    *func = reinterpret_cast<const void *>(&bf_terms_kernel);
+    *grid = dim3(a.pairs_pad / kBlock, a.nt);
+    *block = dim3(kBlock);
+    return hipSuccess;
+}
+
+hipError_t bf_launch_terms(const bf_terms_args &a, hipStream_t stream)
+{
+    const void *func;
+    dim3 grid, block;
+    const hipError_t e = bf_prepare_terms(a, &func, &grid, &block);
+    if (e != hipSuccess || func == nullptr) return e;
+    void *params[] = {const_cast<bf_terms_args *>(&a)};
+    return hipLaunchKernel(func, grid, block, params, 0, stream);
 }
 
 hipError_t bf_launch_rows(const bf_rows_args &a_in, bool out16, int waves_per_block, int rows_per_wave,

@@ -233,8 +233,7 @@ int dcs_bf_generate_and_beamform_dt(dcs_bf_context *ctx, const float *dt, uint32
  *           small table a pre-pass kernel writes just before (form 3; at most 8 time steps per launch,
  *           nontemporal stores): the pre-pass costs ~3 us and takes ~12 of 41 VALU operations per fp32
  *           coefficient out of the main kernel.  form 0 (default) picks by size: the table for launches
- *           of >= 1 GiB of output, per-workgroup terms for smaller ones (and always inside
- *           dcs_bf_stream_* graphs, which hold one kernel node);
+ *           of >= 2 GiB of output, per-workgroup terms for smaller ones;
  *   form 2 "rows":  the terms table for any number of time steps, then short waves
  *           (waves_per_block adjacent 1-KiB tiles x rows_per_wave channel rows)
  *           stream the tensor in address order.
@@ -291,7 +290,8 @@ int dcs_bf_autotune(dcs_bf_context *ctx, int bitwidth, void *d_out, size_t out_b
 int dcs_bf_gpu_utilisation(const struct dcs_bf_params *p, float kernel_ms, float out[2]);
 
 /* ---- streaming (BASELINE config 5) -------------------------------------- */
-/* A hipGraph with one kernel node (generate one time step of the channel slab
+/* A hipGraph with one kernel node -- two for slabs of >= 2 GiB, whose pairs' terms come from a pre-pass
+ * kernel (dcs_bf_tuning::form) -- (generate one time step of the channel slab
  * [c0, c0+nc), all (antenna, beam), in place in d_out).  Each tick rewrites the
  * node's arguments in the instantiated graph (fDeltaTime of time index t; the
  * delay-table buffer) and replays it on `stream` -- no host synchronisation.  A

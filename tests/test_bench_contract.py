@@ -14,7 +14,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 ROOT = Path(__file__).resolve().parent.parent
-SMALL = ["--ant", "16", "--beams-per-gpu", "64", "--chan", "2048", "--steps", "5", "--warmup", "2", "--no-extras"]
+SMALL = ["--ant", "16", "--beams-per-gpu", "64", "--chan", "2048", "--steps", "5", "--warmup", "2"]
 
 
 def _free_port() -> str:
@@ -50,24 +50,37 @@ def _common(d, n_gpus=1):
         assert k in r, k
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
-    assert r["traffic"] is None  # PMC traffic is committed for the headline workload only; nothing is invented
+    assert r["traffic"] is None and r["traffic_source"] is None  # PMC traffic is committed for the headline workload only; nothing is invented
+    pr = d["per_rank"]
+    assert len(pr) == n_gpus and sorted(x["rank"] for x in pr) == list(range(n_gpus))
+    for x in pr:
+        assert x["kernel_ms"] > 0 and x["wall_ms_per_step"] > 0 and x["geometry"]
+    assert "rccl_world_size" in d
     # value = coefficients of all ranks' steps / wall time; rank 0's kernel-only rate cannot be lower than its share
     assert 0 < d["value"] * 8 / n_gpus <= r["achieved"] * 1.001
 
 
 def test_single_gpu_line_with_cpu_baseline():
-    d = _run(["--cpu-seconds", "0.3"])
+    d = _run(["--cpu-seconds", "0.3", "--sustain-seconds", "0.4"])
     _common(d)
-    assert d["config"]["collective"] == "none"
+    assert d["config"]["collective"] == "none" and d["rccl_world_size"] is None
+    am = d["also_measured"]
+    su = am["sustained"]
+    assert su["seconds"] >= 0.4 and su["value"] > 0 and su["launches"] >= 50 and 0 < su["frac_of_hbm_peak"] < 1
+    st = am["streaming_cfg5"]
+    assert st["cadence_target_us"] == 200.0 and st["full_tensor_period_us"] > 0
+    assert st["largest_slab_at_200us"] is None or st["largest_slab_at_200us"]["period_us"] <= 200.0
+    assert am["fp16_output"]["math_mode"] == 0 and am["fp16_output_b16_arithmetic"]["math_mode"] == 4
+    assert am["fused_generate_and_beamform"]["value"] > 0
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] == 1 and c["unit"] == "Gcoeff/s" and c["value"] > 0 and c["sample"]
     assert c["gpu_vs_oracle_spot_check"]["over_1ulp"] == 0
 
 
 def test_collective_control_flow_over_rccl_world_of_one():
-    d = _run(["--force-collective", "--no-cpu-baseline", "--check-all-ranks"])
+    d = _run(["--force-collective", "--no-cpu-baseline", "--check-all-ranks", "--no-extras"])
     _common(d)
-    assert d["config"]["collective"] == "RCCL broadcast"
+    assert d["config"]["collective"] == "RCCL broadcast" and d["rccl_world_size"] == 1
     assert "cpu_baseline" not in d
 
 
@@ -80,12 +93,12 @@ def test_two_ranks_sharing_the_gpu_over_gloo():
         env.pop(k, None)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", _free_port(), str(ROOT / "bench.py"), "--gpus", "2", *SMALL, "--backend", "gloo", "--shared-device",
-           "--check-all-ranks", "--no-cpu-baseline"]
+           "--check-all-ranks", "--no-cpu-baseline", "--no-extras"]
     res = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900, cwd=str(ROOT))
     assert res.returncode == 0, res.stderr[-2000:]
     lines = [l for l in res.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, res.stdout[:500]
     d = json.loads(lines[0])
     _common(d, n_gpus=2)
-    assert "gloo" in d["config"]["collective"] and "REHEARSAL" in d["config"]["collective"]
+    assert "gloo" in d["config"]["collective"] and "REHEARSAL" in d["config"]["collective"] and d["rccl_world_size"] is None
     assert d["config"]["coeffs_per_step"] == 2 * 16 * 64 * 2048

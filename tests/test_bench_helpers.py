@@ -28,6 +28,7 @@ def test_committed_pmc_traffic_matches_workload():
     d = json.loads((ROOT / "profiles" / "pmc_write_size.json").read_text())
     algo = 8 * 64 * 1024 * 32768
     assert d["algorithmic_bytes_per_launch"] == algo
-    t = bench.pmc_traffic(algo)
+    t, src = bench.pmc_traffic(algo)
     assert t is not None and 0.99 < t / algo < 1.05  # measured HBM bytes ~ algorithmic bytes
-    assert bench.pmc_traffic(algo // 2) is None       # another workload: no number is invented
+    assert "pmc_write_size.json" in src and "rocprofv3 --pmc" in src  # the JSON line says where the number comes from
+    assert bench.pmc_traffic(algo // 2) == (None, None)  # another workload: no number is invented

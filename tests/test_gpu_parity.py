@@ -1157,7 +1157,7 @@ def test_b16_arithmetic_form_in_the_generator(gpu, oracle, kernel):
 
 
 def test_autotune_measures_a_large_shape_once(gpu, oracle):
-    """dcs_bf_autotune on a tensor large enough to be tuned (1 GiB: 64 x 256 x 8192): the first call measures (~1 s), the
+    """dcs_bf_autotune on a tensor large enough to be tuned (2 GiB: 64 x 256 x 16384): the first call measures (~1 s), the
     second returns the cached choice at once, dcs_bf_set_tuning(NULL) forgets it; whatever was chosen, sampled rows are
     the oracle's."""
     import time
@@ -1165,7 +1165,7 @@ def test_autotune_measures_a_large_shape_once(gpu, oracle):
     from dc_sand_amd import BeamformerParameters
     from dc_sand_amd.generator import SteeringCoefficientGenerator
 
-    bp = BeamformerParameters(NR_CHANNELS=8192, NR_STATIONS=64, NR_BEAMS=256)
+    bp = BeamformerParameters(NR_CHANNELS=16384, NR_STATIONS=64, NR_BEAMS=256)
     op = oracle.params_from(bp)
     table = rand_table(bp.n_pairs, seed=91)
     g = SteeringCoefficientGenerator(bp)
@@ -1182,7 +1182,7 @@ def test_autotune_measures_a_large_shape_once(gpu, oracle):
     g.generate(buf, nbytes, t0=9, nt=1)
     row = bp.n_pairs * 8
     host = np.empty((bp.NR_STATIONS, bp.NR_BEAMS, 2), dtype=np.float32)
-    for ch in (0, 4097, 8191):
+    for ch in (0, 4097, 16383):
         gpu.memcpy_dtoh(host, int(buf) + ch * row)
         assert oracle.max_ulp(host, oracle.generate(op, table, 9, 1, ch, 1), 1)[1] == 0
     g.set_tuning()  # forgets the cached choice

@@ -9,8 +9,18 @@ import sys
 R = "/root/repo/"
 tag, bench_json, rnd = sys.argv[1], sys.argv[2], sys.argv[3]  # e.g. prof5 bench5.json r01
 f = glob.glob(R + f"gpurun_out/{tag}_kt/runc/*_kernel_trace.csv")[0]
-PROD = "false, 0>(bf_tiled_args)"  # production symbol; dcs_bf_autotune's trial launches run as <..., 1>
-rows = [r for r in csv.DictReader(open(f)) if "bf_tiled_kernel<false," in r["Kernel_Name"] and PROD in r["Kernel_Name"]]
+import re
+
+# production symbol of the fp32 generator: bf_tiled_kernel<false, TPB, NT, ALIGNED, NOMATH=false, TAG=0, INL, TERMS, HALF>;
+# dcs_bf_autotune's trial launches run as <..., TAG=1, ...>
+PROD_RE = re.compile(r"bf_tiled_kernel<false, \d, (true|false), (true|false), false, 0, (true|false), (true|false), false>")
+
+
+def is_prod(name):
+    return PROD_RE.search(name) is not None
+
+
+rows = [r for r in csv.DictReader(open(f)) if is_prod(r["Kernel_Name"])]
 bench_rows = rows[-60:]  # 10 warm-up + 50 timed
 d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in bench_rows]
 timed = d[10:]
@@ -26,7 +36,7 @@ b = json.loads(open(R + "gpurun_out/" + bench_json).read())
 res = {}
 for d_, name in ((f"{tag}_pmc_w", "WRITE_SIZE"), (f"{tag}_pmc_f", "FETCH_SIZE")):
     ff = glob.glob(R + f"gpurun_out/{d_}/runc/*_counter_collection.csv")[0]
-    v = [float(r["Counter_Value"]) for r in csv.DictReader(open(ff)) if "bf_tiled_kernel<false," in r["Kernel_Name"] and PROD in r["Kernel_Name"] and r["Counter_Name"] == name]
+    v = [float(r["Counter_Value"]) for r in csv.DictReader(open(ff)) if is_prod(r["Kernel_Name"]) and r["Counter_Name"] == name]
     res[name] = (len(v), st.mean(v))
     shutil.copy(ff, R + f"profiles/{rnd}_pmc_{name.lower()}_counter_collection.csv")
 algo = 17179869184
@@ -36,6 +46,8 @@ json.dump(
     {
         "workload": "64ant x 1024beam x 32768chan, fp32, one time step per launch",
         "kernel": vg["Kernel_Name"],
+        "round": rnd,
+        "launch_geometry": b["config"]["launch_geometry"],
         "algorithmic_bytes_per_launch": algo,
         "hbm_write_bytes_per_launch": w,
         "hbm_read_bytes_per_launch": fr,
@@ -65,8 +77,9 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -- python3 bench.py --steps 6 --w
                                                                          -> {rnd}_pmc_*_counter_collection.csv, pmc_write_size.json
 ```
 
-Dominant kernel: `bf_tiled_kernel<false, 1, true, true, false, 0>` (fp32, 1 tile per workgroup, nontemporal stores; the
-`<..., 1>` rows of the stats file are the same code under the tuner's symbol: `dcs_bf_autotune`'s trial launches), launch
+Dominant kernel: `{vg['Kernel_Name'].split('(')[1] if False else vg['Kernel_Name'][:100]}` (fp32, 1 tile per workgroup, nontemporal stores,
+terms-table variant: its pre-pass `bf_terms_kernel` is the other kernel of every step, ~3 us; the `<..., 1, ...>` rows of the stats file
+are the same code under the tuner's symbol: `dcs_bf_autotune`'s trial launches), launch
 geometry {b['config']['launch_geometry']}: {vg['VGPR_Count']} VGPRs, {vg['LDS_Block_Size']} B LDS, scratch {vg['Scratch_Size']}, > 99 % of GPU time.
 
 | quantity | value |
