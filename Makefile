@@ -8,8 +8,8 @@
 HIPCC   ?= /opt/rocm/bin/hipcc
 PYTHON  ?= python
 LIB     := dc_sand_amd/csrc/libdcs_beamformer.so
-SRCS    := dc_sand_amd/csrc/bf_kernels.hip dc_sand_amd/csrc/bf_capi.hip
-HDRS    := dc_sand_amd/csrc/bf_kernels.h dc_sand_amd/csrc/bf_math.h include/dcs_beamformer.h
+SRCS    := dc_sand_amd/csrc/bf_kernels.hip dc_sand_amd/csrc/bf_beamform_mfma.hip dc_sand_amd/csrc/bf_capi.hip
+HDRS    := dc_sand_amd/csrc/bf_kernels.h dc_sand_amd/csrc/bf_math.h dc_sand_amd/csrc/bf_device.h include/dcs_beamformer.h
 # -ffp-contract=off is part of the numerical contract; keep in step with dc_sand_amd/build.py
 HIPFLAGS := --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-fast-math -fno-slp-vectorize -fPIC -fvisibility=hidden \
             -Wall -Wextra -Wno-unused-parameter

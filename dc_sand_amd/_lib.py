@@ -90,6 +90,8 @@ SIGNATURES = [
     ("dcs_bf_generate_slab_dt", c_int, [_VP, c_int, POINTER(c_float), c_uint32, c_uint32, c_uint32, _VP, c_size_t, _VP]),
     ("dcs_bf_generate_at", c_int, [_VP, c_int, c_int, POINTER(Timespec), POINTER(Timespec), c_uint32, _VP, c_size_t, _VP]),
     ("dcs_bf_generate_and_beamform_dt", c_int, [_VP, POINTER(c_float), c_uint32, _VP, c_size_t, _VP, c_size_t, _VP]),
+    ("dcs_bf_beamform_accumulated", c_int, [_VP, c_uint64, c_uint32, _VP, c_size_t, _VP, c_size_t, _VP]),
+    ("dcs_bf_beamform_accumulated_dt", c_int, [_VP, c_float, c_uint32, _VP, c_size_t, _VP, c_size_t, _VP]),
     ("dcs_bf_set_tuning", c_int, [_VP, _VP]),
     ("dcs_bf_autotune", c_int, [_VP, c_int, _VP, c_size_t, _VP, _VP]),
     ("dcs_bf_generate_and_beamform", c_int, [_VP, c_uint64, c_uint32, _VP, c_size_t, _VP, c_size_t, _VP]),

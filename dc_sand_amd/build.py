@@ -18,8 +18,8 @@ from pathlib import Path
 
 CSRC = Path(__file__).resolve().parent / "csrc"
 LIB = CSRC / "libdcs_beamformer.so"
-SOURCES = ["bf_kernels.hip", "bf_capi.hip"]
-HEADERS = ["bf_kernels.h", "bf_math.h", "../../include/dcs_beamformer.h"]
+SOURCES = ["bf_kernels.hip", "bf_beamform_mfma.hip", "bf_capi.hip"]
+HEADERS = ["bf_kernels.h", "bf_math.h", "bf_device.h", "../../include/dcs_beamformer.h"]
 ARCH = "gfx950"
 
 

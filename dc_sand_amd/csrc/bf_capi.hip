@@ -982,6 +982,69 @@ int dcs_bf_generate_and_beamform_dt(dcs_bf_context *c, const float *dt, uint32_t
     return beamform_impl(c, dt_source{dt, 0}, nt, d_antenna, antenna_bytes, d_beams, beams_bytes, stream);
 }
 
+namespace {
+int beamform_acc_impl(dcs_bf_context *c, const dt_source &src, uint32_t nt, const int8_t *d_antenna, size_t antenna_bytes,
+                      float *d_beams, size_t beams_bytes, void *stream)
+{
+    if (!c || (nt && (!d_antenna || !d_beams))) return DCS_ERR_INVALID_ARGUMENT;
+    DCS_CHECK_DEVICE(c);
+    if (nt % 16u) return DCS_ERR_INVALID_ARGUMENT; // INTERNAL_TIME_SAMPLES, BeamformerParameters.h:51
+    if (!c->table_set) return DCS_ERR_NOT_READY;
+    const uint32_t A = (uint32_t)c->p.nr_stations, B = (uint32_t)c->p.nr_beams, C = (uint32_t)c->p.nr_channels;
+    if (A > 256u) return DCS_ERR_UNSUPPORTED; // the coefficient planes of one workgroup must fit 64 KiB of LDS
+    if (antenna_bytes < (size_t)A * C * nt * 2u) return DCS_ERR_INVALID_ARGUMENT;
+    if (beams_bytes < (size_t)B * C * nt * 2u * sizeof(float)) return DCS_ERR_INVALID_ARGUMENT;
+    if ((reinterpret_cast<uintptr_t>(d_antenna) & 15u) || (reinterpret_cast<uintptr_t>(d_beams) & 7u))
+        return DCS_ERR_INVALID_ARGUMENT;
+    if (nt == 0) return DCS_OK;
+    hipStream_t s = as_stream(stream);
+    {
+        int st_alloc = ensure_terms(c);
+        if (st_alloc != DCS_OK) return st_alloc;
+    }
+    const float *dt_dev = nullptr;
+    int st = stage_dt(c, src, 0, 1, s, &dt_dev); // ONE coefficient time for the whole block of samples
+    if (st != DCS_OK) return st;
+    DCS_TRY(hipMemsetAsync(c->d_flags, 0, sizeof(uint32_t), s));
+    bf_bform_terms_args ta;
+    std::memset(&ta, 0, sizeof(ta));
+    ta.delays = c->d_table[c->cur];
+    ta.terms = c->d_terms;
+    ta.flags = c->d_flags;
+    ta.dt_dev = dt_dev;
+    ta.n_pairs = c->n_pairs;
+    ta.A = A;
+    ta.B = B;
+    ta.nt = 1;
+    ta.k = c->k;
+    DCS_TRY(bf_launch_bform_terms(ta, s));
+    bf_bacc_args a;
+    std::memset(&a, 0, sizeof(a));
+    a.terms = c->d_terms;
+    a.flags = c->d_flags;
+    a.ant = d_antenna;
+    a.beams = d_beams;
+    a.A = A;
+    a.B = B;
+    a.C = C;
+    a.nT16 = nt / 16u;
+    a.k = c->k;
+    return (int)bf_launch_beamform_acc(a, s);
+}
+} // namespace
+
+int dcs_bf_beamform_accumulated(dcs_bf_context *c, uint64_t t_coeff, uint32_t nt, const int8_t *d_antenna, size_t antenna_bytes,
+                                float *d_beams, size_t beams_bytes, void *stream)
+{
+    return beamform_acc_impl(c, dt_source{nullptr, t_coeff}, nt, d_antenna, antenna_bytes, d_beams, beams_bytes, stream);
+}
+
+int dcs_bf_beamform_accumulated_dt(dcs_bf_context *c, float dt_coeff, uint32_t nt, const int8_t *d_antenna, size_t antenna_bytes,
+                                   float *d_beams, size_t beams_bytes, void *stream)
+{
+    return beamform_acc_impl(c, dt_source{&dt_coeff, 0}, nt, d_antenna, antenna_bytes, d_beams, beams_bytes, stream);
+}
+
 int dcs_bf_autotune(dcs_bf_context *c, int bitwidth, void *d_out, size_t out_bytes, void *stream,
                     dcs_bf_tuning *chosen)
 {

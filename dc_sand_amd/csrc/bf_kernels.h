@@ -120,6 +120,19 @@ struct bf_beamform_args {
 };
 hipError_t bf_launch_beamform(const bf_beamform_args &a, hipStream_t stream);
 
+// Beamformer with coefficient reuse on the matrix cores (bf_beamform_mfma.hip): the coefficients of ONE time
+// (terms table [A][B] from bf_launch_bform_terms with nt = 1) applied to nT16 blocks of 16 samples.
+struct bf_bacc_args {
+    const float *terms;    // [A][B][2]
+    const uint32_t *flags; // [1]: highest pair class of the table
+    const int8_t *ant;     // [C][nT16][A][16][2]
+    float *beams;          // [C][nT16][B][16][2]
+    uint32_t A, B, C, nT16;
+    uint32_t tiles_per_wg, n_bgroups, n_tgroups; // filled by the launcher
+    dcs_bf_consts k;
+};
+hipError_t bf_launch_beamform_acc(const bf_bacc_args &a, hipStream_t stream);
+
 // One coefficient per lane, one time step (reference kernel a1's shape).
 struct bf_naive_args {
     const dcs_delay_vals *delays;

@@ -169,6 +169,25 @@ class SteeringCoefficientGenerator:
             "dcs_bf_generate_and_beamform",
         )
 
+    def beamform_accumulated(self, d_antenna, antenna_bytes: int, d_beams, beams_bytes: int, nt: int, t_coeff: int | None = None,
+                             dt_coeff: float | None = None, stream=None) -> None:
+        """Beamformer with coefficient reuse on the matrix cores (``dcs_bf_beamform_accumulated``): the coefficients of
+        ONE time (time index ``t_coeff`` or fDeltaTime ``dt_coeff``) applied to ``nt`` samples; table indexed [beam*A + antenna]."""
+        if (t_coeff is None) == (dt_coeff is None):
+            raise ValueError("give exactly one of t_coeff / dt_coeff")
+        if dt_coeff is None:
+            check(
+                _lib.lib().dcs_bf_beamform_accumulated(c_void_p(self._h), int(t_coeff), int(nt), c_void_p(int(d_antenna)), int(antenna_bytes),
+                                                       c_void_p(int(d_beams)), int(beams_bytes), _s(stream)),
+                "dcs_bf_beamform_accumulated",
+            )
+        else:
+            check(
+                _lib.lib().dcs_bf_beamform_accumulated_dt(c_void_p(self._h), float(np.float32(dt_coeff)), int(nt), c_void_p(int(d_antenna)),
+                                                          int(antenna_bytes), c_void_p(int(d_beams)), int(beams_bytes), _s(stream)),
+                "dcs_bf_beamform_accumulated_dt",
+            )
+
     def set_tuning(self, form: int = 0, nontemporal: int = -1, chan_per_block: int = 0, tiles_per_block: int = 0,
                    waves_per_block: int = 0, rows_per_wave: int = 0, xcd_remap: int = -1, probe_nomath: bool = False,
                    rows_same_tile: int = -1, probe_pace: int = 0, math_mode: int = 0, wg_per_cu: int = 0) -> None:

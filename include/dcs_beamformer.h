@@ -220,6 +220,25 @@ int dcs_bf_generate_and_beamform(dcs_bf_context *ctx, uint64_t t0, uint32_t nt, 
 int dcs_bf_generate_and_beamform_dt(dcs_bf_context *ctx, const float *dt, uint32_t nt, const int8_t *d_antenna,
                                     size_t antenna_bytes, float *d_beams, size_t beams_bytes, void *stream);
 
+/* Beamformer with coefficient REUSE -- the "general version" of the fused kernel.  The reference
+ * regenerates every coefficient for every sample and only MODELS what a deployed beamformer does: new
+ * coefficients every ACCUMULATIONS_BEFORE_NEW_COEFFS time units (BeamformerParameters.h:17; the utilisation
+ * model BCT.cu:426-448).  Here the coefficients of ONE time -- time index t_coeff (fDeltaTime as
+ * dcs_bf_delta_times gives it), or fDeltaTime by value -- are generated once per (channel, antenna, beam), into
+ * LDS, never HBM, and applied to nt samples (a multiple of 16; tensors and table ordering exactly as
+ * dcs_bf_generate_and_beamform):
+ *   beams[c][t/16][b][t%16] = ( sum_a cos(rot[a][b][c]) * re[c][t][a] , sum_a sin(rot[a][b][c]) * im[c][t][a] )
+ * Per channel two real contractions over the antennas on the fp32 matrix cores (v_mfma_f32_16x16x4_f32):
+ * exact fp32 products accumulated as an fma chain in antenna order, so the result differs from the verifier's
+ * loop with the coefficient held (BCT.cu:363-414: sum += coeff * sample, multiply and add rounded separately)
+ * by the chain's roundings only -- |difference| <= 2e-5 * nr_stations against the reference's tolerance of 1e-1
+ * (runBeamformerTests.cpp:15).  nr_stations <= 256; d_antenna 16-byte aligned.  Not capturable (stages one
+ * fDeltaTime through pinned memory; allocates its terms table on first use). */
+int dcs_bf_beamform_accumulated(dcs_bf_context *ctx, uint64_t t_coeff, uint32_t nt, const int8_t *d_antenna,
+                                size_t antenna_bytes, float *d_beams, size_t beams_bytes, void *stream);
+int dcs_bf_beamform_accumulated_dt(dcs_bf_context *ctx, float dt_coeff, uint32_t nt, const int8_t *d_antenna,
+                                   size_t antenna_bytes, float *d_beams, size_t beams_bytes, void *stream);
+
 /* Launch-geometry knobs (all 0 / NULL = the library's shape-aware defaults, DESIGN.md "launch
  * geometry": per launch the library looks at the tiles per row, the workgroups the launch makes and
  * its bytes -- fp32: 1 tile x 12 channels per workgroup and at most 6 workgroups per CU when there is

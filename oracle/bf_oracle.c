@@ -482,6 +482,46 @@ void dcs_oracle_beamform_dt(const struct dcs_oracle_params *p,
     beamform_impl(p, delays, dt, nt, pi8InAntData, pfCorrectBeams);
 }
 
+/* BeamformerCoefficientTest.cu:363-414 with the coefficient HELD: the steering coefficient of
+ * (channel, beam, antenna) is evaluated once, at fDeltaTime dt_coeff (:319-328, table ordering :311),
+ * and applied to all nt samples -- what ACCUMULATIONS_BEFORE_NEW_COEFFS (BeamformerParameters.h:17;
+ * the utilisation model :426-448) assumes of a deployed beamformer; the reference has no kernel for it.
+ * The sums are the verifier's: antenna order, fBeamSum += coeff * sample (multiply and add rounded
+ * separately). */
+void dcs_oracle_beamform_accumulated(const struct dcs_oracle_params *p,
+                                     const struct dcs_oracle_delay_vals *delays, float dt_coeff, size_t nt,
+                                     const int8_t *pi8InAntData, float *pfCorrectBeams)
+{
+    const size_t NR_CHANNELS = (size_t)p->nr_channels;
+    const size_t NR_STATIONS = (size_t)p->nr_stations;
+    const size_t NR_BEAMS = (size_t)p->nr_beams;
+    const size_t NR_SAMPLES_PER_CHANNEL = nt;
+    const size_t INTERNAL_TIME_SAMPLES = 16;
+    float *coeff = malloc(NR_STATIONS * 2 * sizeof(float));
+    for (size_t c = 0; c < NR_CHANNELS; c++) {
+        for (size_t b = 0; b < NR_BEAMS; b++) {
+            for (size_t a = 0; a < NR_STATIONS; a++)
+                dcs_oracle_coeff(p, delays[b * NR_STATIONS + a], dt_coeff, c, &coeff[2 * a], &coeff[2 * a + 1]);
+            for (size_t t = 0; t < NR_SAMPLES_PER_CHANNEL; t++) {
+                const size_t t_ex = t / INTERNAL_TIME_SAMPLES, t_in = t % INTERNAL_TIME_SAMPLES;
+                size_t iBeamIndex = c * NR_SAMPLES_PER_CHANNEL * NR_BEAMS + t_ex * NR_BEAMS * INTERNAL_TIME_SAMPLES + b * INTERNAL_TIME_SAMPLES + t_in;
+                float fBeamSumReal = 0;
+                float fBeamSumImag = 0;
+                for (size_t a = 0; a < NR_STATIONS; a++) {
+                    size_t ulAntSampleIndex = 2 * (c * NR_SAMPLES_PER_CHANNEL * NR_STATIONS + t_ex * NR_STATIONS * INTERNAL_TIME_SAMPLES + a * INTERNAL_TIME_SAMPLES + t_in);
+                    int8_t iRealAntSample = pi8InAntData[ulAntSampleIndex];
+                    int8_t iImagAntSample = pi8InAntData[ulAntSampleIndex + 1];
+                    fBeamSumReal += coeff[2 * a] * iRealAntSample;
+                    fBeamSumImag += coeff[2 * a + 1] * iImagAntSample;
+                }
+                pfCorrectBeams[2 * iBeamIndex] = fBeamSumReal;
+                pfCorrectBeams[2 * iBeamIndex + 1] = fBeamSumImag;
+            }
+        }
+    }
+    free(coeff);
+}
+
 /* IEEE binary16 round-to-nearest-even of an fp32 (what __floats2half2_rn does
  * per element, BeamformerKernels.cu:113,182). */
 uint16_t dcs_oracle_f32_to_f16_rn(float x)

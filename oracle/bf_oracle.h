@@ -169,6 +169,13 @@ void dcs_oracle_beamform_dt(const struct dcs_oracle_params *p,
                             const struct dcs_oracle_delay_vals *delays, const float *dt, size_t nt,
                             const int8_t *antenna_data, float *out);
 
+/* The verifier's beamformer (:363-414) with the coefficient HELD at one fDeltaTime for all nt samples
+ * (what ACCUMULATIONS_BEFORE_NEW_COEFFS models; the reference has no kernel for it): the expectation of
+ * dcs_bf_beamform_accumulated.  Same tensors and table ordering as dcs_oracle_beamform. */
+void dcs_oracle_beamform_accumulated(const struct dcs_oracle_params *p,
+                                     const struct dcs_oracle_delay_vals *delays, float dt_coeff, size_t nt,
+                                     const int8_t *antenna_data, float *out);
+
 /* fp16 (f2): IEEE binary16 round-to-nearest-even of an fp32, as
  * __floats2half2_rn does per element (BeamformerKernels.cu:113,182). */
 uint16_t dcs_oracle_f32_to_f16_rn(float x);

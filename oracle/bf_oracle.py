@@ -72,6 +72,7 @@ def lib() -> ctypes.CDLL:
         L.dcs_oracle_generate_dt.argtypes = [P, c_void_p, c_void_p, c_size_t, c_size_t, c_size_t, c_void_p]
         L.dcs_oracle_generate_at.argtypes = [P, c_void_p, c_void_p, Timespec, c_size_t, c_size_t, c_size_t, c_void_p]
         L.dcs_oracle_beamform_dt.argtypes = [P, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]
+        L.dcs_oracle_beamform_accumulated.argtypes = [P, c_void_p, c_float, c_size_t, c_void_p, c_void_p]
         L.dcs_oracle_compare_generated.argtypes = [P, c_void_p, c_void_p, c_size_t, c_size_t, c_size_t, c_void_p, c_int, c_int,
                                                    POINTER(c_uint64 * 4), POINTER(c_uint32), POINTER(c_int64)]
         L.dcs_oracle_compare_generated.restype = c_double
@@ -260,6 +261,18 @@ def beamform_dt(p: OracleParams, delays_beam_major: np.ndarray, dt, antenna_data
     assert ant.size == p.nr_channels * nt * p.nr_stations * 2
     out = np.empty((p.nr_channels, nt // 16, p.nr_beams, 16, 2), dtype=np.float32)
     lib().dcs_oracle_beamform_dt(byref(p), c_void_p(delays.ctypes.data), c_void_p(dt.ctypes.data), nt, c_void_p(ant.ctypes.data), c_void_p(out.ctypes.data))
+    return out
+
+
+def beamform_accumulated(p: OracleParams, delays_beam_major: np.ndarray, dt_coeff: float, nt: int, antenna_data: np.ndarray) -> np.ndarray:
+    """Expected beams float [chan][nt/16][beam][16][2] with the coefficient of ONE fDeltaTime held for all nt samples."""
+    assert nt % 16 == 0
+    delays = np.ascontiguousarray(delays_beam_major, dtype=delay_vals_dtype)
+    ant = np.ascontiguousarray(antenna_data, dtype=np.int8)
+    assert ant.size == p.nr_channels * nt * p.nr_stations * 2
+    out = np.empty((p.nr_channels, nt // 16, p.nr_beams, 16, 2), dtype=np.float32)
+    lib().dcs_oracle_beamform_accumulated(byref(p), c_void_p(delays.ctypes.data), float(np.float32(dt_coeff)), nt, c_void_p(ant.ctypes.data),
+                                          c_void_p(out.ctypes.data))
     return out
 
 

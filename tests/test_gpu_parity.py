@@ -1190,3 +1190,85 @@ def test_autotune_measures_a_large_shape_once(gpu, oracle):
     g.autotune(buf, nbytes)
     assert time.perf_counter() - t0 > 0.2
     g.close()
+
+
+# ---- beamformer with coefficient reuse on the matrix cores ("general version")
+@pytest.mark.parametrize("A,B,C,nt", [(64, 16, 64, 256), (64, 16, 5, 32), (64, 64, 7, 64), (64, 40, 3, 48), (8, 4, 5, 16), (37, 21, 9, 48),
+                                       (130, 3, 4, 16), (4, 40, 7, 32), (9, 5, 3, 16), (129, 33, 2, 32), (256, 17, 2, 16), (1, 1, 1, 16),
+                                       (66, 70, 2, 80)])
+def test_beamform_accumulated_on_the_matrix_cores(gpu, oracle, A, B, C, nt):
+    """dcs_bf_beamform_accumulated: the coefficients of ONE time applied to nt samples as two real contractions over the
+    antennas on v_mfma_f32_16x16x4_f32, against the verifier's beamformer with the coefficient held
+    (BeamformerCoefficientTest.cu:363-414).  The matrix instruction is an fp32 fma chain in antenna order, the verifier
+    multiplies and adds with separate roundings, and each coefficient is within 1 ULP: |difference| <= 2e-5 * A (the
+    bound the per-sample fused kernel is held to); the reference's own tolerance is 1e-1 (runBeamformerTests.cpp:15).
+    Shapes cover every beam-tile count (1, 2, 4 per workgroup), ragged antennas / beams / sample blocks, several
+    64-antenna chunks and the 256-antenna limit."""
+    from dc_sand_amd import BeamformerParameters
+    from dc_sand_amd.generator import SteeringCoefficientGenerator, delta_times, simulate_input
+
+    bp = BeamformerParameters(NR_CHANNELS=C, NR_STATIONS=A, NR_BEAMS=B, NR_SAMPLES_PER_CHANNEL=nt)
+    op = oracle.params_from(bp)
+    seeded = (A, B, C, nt) != (64, 16, 64, 256)
+    table = rand_table(bp.n_pairs, seed=A + B) if seeded else simulate_input(bp)  # indexed [b*A + a]
+    ant = oracle.simulate_antenna_data(op, nt)
+    if seeded:
+        ant = np.random.default_rng(A).integers(-128, 128, size=ant.shape, dtype=np.int8)
+    t_coeff = 9
+    exp = oracle.beamform_accumulated(op, table, delta_times(bp, t_coeff, 1)[0], nt, ant)
+    g = SteeringCoefficientGenerator(bp)
+    g.upload_delays(table)
+    d_ant = gpu.mem_alloc(ant.nbytes)
+    gpu.memcpy_htod(d_ant, ant)
+    d_beams = gpu.mem_alloc(exp.nbytes + 64)
+    gpu.memset(d_beams, 0xFF, exp.nbytes + 64)
+    g.beamform_accumulated(d_ant, ant.nbytes, d_beams, exp.nbytes, nt, t_coeff=t_coeff)
+    host = np.empty(exp.nbytes + 64, dtype=np.uint8)
+    gpu.memcpy_dtoh(host, d_beams)
+    assert np.all(host[exp.nbytes:] == 0xFF)
+    got = host[:exp.nbytes].view(np.float32).reshape(exp.shape)
+    assert np.all(np.isfinite(got))
+    diff = np.abs(got - exp)
+    assert diff.max() <= 2e-5 * A + 1e-6, diff.max()
+    assert oracle.compare(got, exp, 1e-1) == -1
+    # fDeltaTime by value gives the same bits
+    g.beamform_accumulated(d_ant, ant.nbytes, d_beams, exp.nbytes, nt, dt_coeff=float(delta_times(bp, t_coeff, 1)[0]))
+    got2 = np.empty(exp.shape, dtype=np.float32)
+    gpu.memcpy_dtoh(got2, d_beams)
+    assert np.array_equal(got2.view(np.uint32), got.view(np.uint32))
+    g.close()
+
+
+def test_beamform_accumulated_slow_class_and_limits(gpu, oracle):
+    """A pair outside the fast path's range sends the coefficient generation down the slow branch (IEEE divide, fp64
+    sincos); more than 256 antennas and sample counts that are not whole 16-sample blocks are refused."""
+    from dc_sand_amd import BeamformerParameters, _lib
+    from dc_sand_amd.generator import SteeringCoefficientGenerator
+
+    bp = BeamformerParameters(NR_CHANNELS=6, NR_STATIONS=9, NR_BEAMS=5, NR_SAMPLES_PER_CHANNEL=32)
+    op = oracle.params_from(bp)
+    table = rand_table(bp.n_pairs, seed=77)
+    table["fDelayRate_sps"][11] = 1e-2
+    table["fDelayRate_sps"][12] = 1e-30
+    ant = np.random.default_rng(3).integers(-128, 128, size=(6, 2, 9, 16, 2), dtype=np.int8)
+    dt = np.float32(0.25)
+    exp = oracle.beamform_accumulated(op, table, dt, 32, ant)
+    g = SteeringCoefficientGenerator(bp)
+    g.upload_delays(table)
+    d_ant = gpu.mem_alloc(ant.nbytes)
+    gpu.memcpy_htod(d_ant, ant)
+    d_beams = gpu.mem_alloc(exp.nbytes)
+    g.beamform_accumulated(d_ant, ant.nbytes, d_beams, exp.nbytes, 32, dt_coeff=float(dt))
+    got = np.empty_like(exp)
+    gpu.memcpy_dtoh(got, d_beams)
+    assert np.abs(got - exp).max() <= 2e-4 * 9
+    with pytest.raises(_lib.DcsError) as e:
+        g.beamform_accumulated(d_ant, ant.nbytes, d_beams, exp.nbytes, 24, t_coeff=0)
+    assert e.value.status == _lib.DCS_ERR_INVALID_ARGUMENT
+    g.close()
+    big = SteeringCoefficientGenerator(BeamformerParameters(NR_CHANNELS=1, NR_STATIONS=257, NR_BEAMS=1))
+    big.upload_delays(rand_table(257))
+    with pytest.raises(_lib.DcsError) as e:
+        big.beamform_accumulated(d_ant, 257 * 32, d_beams, 16 * 8, 16, t_coeff=0)
+    assert e.value.status == _lib.DCS_ERR_UNSUPPORTED
+    big.close()

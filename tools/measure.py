@@ -210,6 +210,27 @@ def cmd_fused(args):
         g.close()
 
 
+def cmd_bfacc(args):
+    """Beamformer with coefficient reuse on the matrix cores: rate against its roofline (int8 samples in + fp32 beams
+    out vs 8 TB/s; fp32 MFMA 2 * 2 * A * B flop per sample vs 155 TFLOP/s)."""
+    for (A, B, C, nt) in ((64, 16, 64, 256), (64, 16, 4096, 256), (64, 16, 4096, 4096), (64, 64, 4096, 256), (64, 256, 1024, 256), (256, 64, 1024, 256),
+                          (64, 1024, 256, 256)):
+        bp = BeamformerParameters(NR_CHANNELS=C, NR_STATIONS=A, NR_BEAMS=B, NR_SAMPLES_PER_CHANNEL=nt)
+        g = SteeringCoefficientGenerator(bp)
+        g.upload_delays(simulate_input(bp))
+        ab, bb = A * C * nt * 2, B * C * nt * 8
+        d_ant, d_beams = device.mem_alloc(ab), device.mem_alloc(bb)
+        device.memset(d_ant, 3, ab)
+        ms = min(per_launch_ms(lambda: g.beamform_accumulated(d_ant, ab, d_beams, bb, nt, t_coeff=1)) for _ in range(2))
+        flop = 4.0 * A * B * C * nt
+        print(f"{A}ant x {B}beam x {C}chan x {nt}samples: {ms * 1e3:.1f} us -> {A * B * C * nt / ms / 1e9:.2f} T coefficient-products/s, "
+              f"{(ab + bb) / ms / 1e9:.2f} TB/s algorithmic ({(ab + bb) / ms / 1e9 / 8 * 100:.1f} % of 8 TB/s), {flop / ms / 1e9:.1f} TFLOP/s fp32 MFMA "
+              f"({flop / ms / 1e9 / 155 * 100:.1f} % of 155)", flush=True)
+        g.close()
+        d_ant.free()
+        d_beams.free()
+
+
 def cmd_stream(args):
     bp, g, _, full, buf = make(SHAPES["cfg3"], 32)
     table = simulate_input(bp)
@@ -375,6 +396,7 @@ def main():
     p.add_argument("--form", type=int, default=1, help="1 = per-workgroup terms, 3 = terms table, 0 = library's choice")
     p.add_argument("--bits", type=int, default=16, choices=[16, 32])
     sub.add_parser("fused")
+    sub.add_parser("bfacc")
     p = sub.add_parser("stream")
     p.add_argument("--model-step-us", type=float, default=200.0)
     sub.add_parser("pmc")
@@ -397,7 +419,7 @@ def main():
     device.require_device()
     device.set_device(0)
     print("device:", device.device_name(0), flush=True)
-    {"geometry": cmd_geometry, "refshape": cmd_refshape, "fp16": cmd_fp16, "fused": cmd_fused, "stream": cmd_stream, "pmc": cmd_pmc,
+    {"geometry": cmd_geometry, "refshape": cmd_refshape, "fp16": cmd_fp16, "fused": cmd_fused, "bfacc": cmd_bfacc, "stream": cmd_stream, "pmc": cmd_pmc,
      "sustained": cmd_sustained, "stores": cmd_stores, "sincos": cmd_sincos}[args.cmd](args)
 
 
