@@ -17,9 +17,17 @@
 //
 // Workgroup = 4 waves = one channel x NBT beam tiles of 16 x a range of 16-sample blocks:
 //   wave w: beam tile w % NBT, sample-block slot w / NBT of each round (4 / NBT blocks per round).
-// W (all antennas x 16*NBT beams, re and im planes, fp32) is generated once per workgroup into LDS from the
-// terms table bf_bform_terms_kernel writes ([a][b]; L2-resident); each round stages its int8 sample blocks
-// into LDS as fp32 planes.  Operand fetch is one ds_read_b32 per operand per MFMA, conflict-free:
+// The waves never wait for each other in the sample loop: a lane reads the (re, im) int8 pair of its own
+// B operand straight from global memory (one 2-byte load per k-step; a wave's 64 lanes cover one 128-byte
+// line, which the waves of the other beam tiles then find in L1), one stage ahead of the matrix pipe, and
+// converts it on the VALU, which idles otherwise.  W (all antennas x 16*NBT beams, re and im planes) is generated
+// once per workgroup into LDS from the terms table bf_bform_terms_kernel writes ([a][b]; L2-resident) -- the
+// kernel's only barrier -- and read from there, one ds_read_b32 per A operand (a quarter of the LDS bandwidth at
+// the full matrix rate).  Few registers, so that 6-8 waves per SIMD hide the memory latencies: loads AND stores
+// take 2-3 thousand cycles under this load, three times a wave's matrix phase; versions that held W in registers
+// (106-138 VGPRs, 3-4 waves per SIMD) or staged samples through LDS behind barriers all stalled at 45 %.  (Two earlier versions staged
+// the samples through LDS -- as fp32 planes, then as int8 -- behind two barriers per round: 45 % of the matrix
+// rate, bound first by LDS bandwidth, then by the waves waiting for each other.)
 //   A operand, lane l: W[beam l & 15][antenna 4j + (l >> 4)]   B operand: S[antenna 4j + (l >> 4)][sample l & 15]
 // C/D: lane l, register r = beam (l >> 4) * 4 + r, sample l & 15.
 // Roofline: int8 samples in (2 B per antenna and sample) + fp32 beams out (8 B per beam and sample) against
@@ -40,13 +48,9 @@ __global__ void __launch_bounds__(kBlock) bf_beamform_acc_kernel(const bf_bacc_a
 {
     constexpr int TPR = 4 / NBT;                                  // 16-sample blocks per round
     constexpr uint32_t WS = 16u * NBT + (NBT > 1 ? 16u : 0u);     // W row stride in floats (padded: no bank conflict)
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    // lds: Wre[A_pad][WS] | Wim[A_pad][WS] | Sre[TPR][kKC][16] | Sim[TPR][kKC][16]
+    constexpr uint32_t NJ = kKC / 4u;                             // k-steps per chunk
+    extern __shared__ __attribute__((aligned(16))) float lds[];   // Wre[A_pad][WS] | Wim[A_pad][WS]
     const uint32_t A_pad = (a.A + 3u) & ~3u;
-    float *Wre = lds;
-    float *Wim = Wre + (size_t)A_pad * WS;
-    float *Sre = Wim + (size_t)A_pad * WS;
-    float *Sim = Sre + (size_t)TPR * kKC * 16u;
 
     uint32_t bid = blockIdx.x;
     const uint32_t bg = bid % a.n_bgroups;
@@ -57,96 +61,121 @@ __global__ void __launch_bounds__(kBlock) bf_beamform_acc_kernel(const bf_bacc_a
     const uint32_t tt0 = tg * a.tiles_per_wg;      // first 16-sample block
     const uint32_t tt1 = min(tt0 + a.tiles_per_wg, a.nT16);
 
-    // ---- W for (channel c, beams [b0, b0 + 16 NBT), all antennas): once per workgroup
-    {
-        const uint32_t cls = a.flags[0]; // highest pair class of the table (bf_bform_terms_kernel)
-        const float fChan = (float)c;
-        const float D = a.k.fDenominator, y = a.k.fRcpDenominator;
-        const uint32_t nb = 16u * NBT;
-        auto fill = [&](auto gen) {
-            for (uint32_t i = threadIdx.x; i < A_pad * nb; i += kBlock) {
-                const uint32_t ant = i / nb, bl = i - ant * nb, b = b0 + bl;
-                float re = 0.0f, im = 0.0f;
-                if (ant < a.A && b < a.B) {
-                    const floatx2 kp = *reinterpret_cast<const floatx2 *>(a.terms + 2u * ((uint64_t)ant * a.B + b));
-                    gen(kp.x, kp.y, re, im);
-                }
-                Wre[ant * WS + bl] = re;
-                Wim[ant * WS + bl] = im;
-            }
-        };
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t bt = wave % NBT, slot = wave / NBT;
+    const uint32_t lm = lane & 15u, lg = lane >> 4;
+
+    const uint32_t cls = a.flags[0]; // highest pair class of the table (bf_bform_terms_kernel)
+    const float fChan = (float)c;
+    const float D = a.k.fDenominator, y = a.k.fRcpDenominator;
+    // one coefficient through the class's path (slow: IEEE divide + fp64 sincos; rare, workgroup-uniform)
+    auto with_generator = [&](auto &&body) {
         if (cls == DCS_CLASS_SLOW) {
-            fill([&](float kx, float ky, float &re, float &im) { coeff_slow(kx, ky, fChan, D, re, im); });
+            body([&](float kx, float ky, float &re, float &im) { coeff_slow(kx, ky, fChan, D, re, im); });
         } else {
             dispatch_fast(a.k.uDiv3Exact != 0u, cls == DCS_CLASS_FAST_LOW, [&](auto div3, auto lowdeg) {
-                fill([&](float kx, float ky, float &re, float &im) {
+                body([&](float kx, float ky, float &re, float &im) {
                     coeff_fast<decltype(div3)::value, decltype(lowdeg)::value>(kx, ky, fChan, D, y, re, im);
                 });
             });
         }
-    }
+    };
 
-    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    const uint32_t bt = wave % NBT, slot = wave / NBT;
-    const uint32_t lm = lane & 15u, lg = lane >> 4;
-    const uint32_t tile_bytes = a.A * 32u; // one [A][16][2] int8 block
-
-    for (uint32_t r0 = tt0; r0 < tt1; r0 += TPR) {
-        floatx4 acc_re = {0.0f, 0.0f, 0.0f, 0.0f}, acc_im = {0.0f, 0.0f, 0.0f, 0.0f};
-        const uint32_t my_tt = r0 + slot;
-        for (uint32_t a0 = 0; a0 < a.A; a0 += kKC) {
-            const uint32_t na = min(kKC, a.A - a0);
-            __syncthreads(); // W is complete (first pass) / the previous chunk's readers are done
-            // ---- stage this round's sample blocks, antennas [a0, a0 + kKC), as fp32 planes; 16 bytes
-            //      (8 samples of one antenna) per thread and pass
-            for (uint32_t e = threadIdx.x; e < (uint32_t)TPR * kKC * 2u; e += kBlock) {
-                const uint32_t r = e / (kKC * 2u), rem = e - r * (kKC * 2u), al = rem >> 1, half = rem & 1u;
-                const uint32_t tt = r0 + r;
-                floatx4 re0 = {0, 0, 0, 0}, re1 = {0, 0, 0, 0}, im0 = {0, 0, 0, 0}, im1 = {0, 0, 0, 0};
-                if (al < na && tt < tt1) {
-                    const uintx4 w = *reinterpret_cast<const uintx4 *>(a.ant + ((uint64_t)c * a.nT16 + tt) * tile_bytes +
-                                                                       (uint64_t)(a0 + al) * 32u + half * 16u);
-                    auto sx = [](uint32_t v, int byte) { return (float)(int8_t)(v >> (8 * byte)); };
-                    re0 = floatx4{sx(w.x, 0), sx(w.x, 2), sx(w.y, 0), sx(w.y, 2)};
-                    im0 = floatx4{sx(w.x, 1), sx(w.x, 3), sx(w.y, 1), sx(w.y, 3)};
-                    re1 = floatx4{sx(w.z, 0), sx(w.z, 2), sx(w.w, 0), sx(w.w, 2)};
-                    im1 = floatx4{sx(w.z, 1), sx(w.z, 3), sx(w.w, 1), sx(w.w, 3)};
-                }
-                float *pr = Sre + ((size_t)r * kKC + al) * 16u + half * 8u;
-                float *pi = Sim + ((size_t)r * kKC + al) * 16u + half * 8u;
-                *reinterpret_cast<floatx4 *>(pr) = re0;
-                *reinterpret_cast<floatx4 *>(pr + 4) = re1;
-                *reinterpret_cast<floatx4 *>(pi) = im0;
-                *reinterpret_cast<floatx4 *>(pi + 4) = im1;
-            }
-            __syncthreads();
-            // ---- 16 k-steps of 4 antennas: two fma chains (re, im) in antenna order
-            const float *wr = Wre + (size_t)(a0 + lg) * WS + bt * 16u + lm;
-            const float *wi = Wim + (size_t)(a0 + lg) * WS + bt * 16u + lm;
-            const float *sr = Sre + ((size_t)slot * kKC + lg) * 16u + lm;
-            const float *si = Sim + ((size_t)slot * kKC + lg) * 16u + lm;
-            if (na == kKC) { // a full chunk: 16 k-steps, unrolled (operand reads run ahead of the matrix pipe)
+    // ---- W for (channel c, beams [b0, b0 + 16 NBT), all antennas) into LDS: once per workgroup, a rolled loop
+    //      (a lane computing its own 16 fragments unrolled cost 178 registers and 36 000 lines of code);
+    //      batches of 8 terms loads in flight together, unconditional on clamped indices and masked afterwards
+    //      (a load under an exec mask makes hipcc wait for it on the spot: one memory latency per load)
+    {
+        float *Wre = lds, *Wim = lds + (size_t)A_pad * WS;
+        const uint32_t nb = 16u * NBT;
+        with_generator([&](auto gen) {
+            constexpr uint32_t kBatch = 8;
+            for (uint32_t i0 = threadIdx.x; i0 < A_pad * nb; i0 += kBlock * kBatch) {
+                floatx2 kp[kBatch];
 #pragma unroll
-                for (uint32_t j = 0; j < kKC / 4u; j++) {
-                    acc_re = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[(size_t)j * 4u * WS], sr[j * 64u], acc_re, 0, 0, 0);
-                    acc_im = __builtin_amdgcn_mfma_f32_16x16x4f32(wi[(size_t)j * 4u * WS], si[j * 64u], acc_im, 0, 0, 0);
+                for (uint32_t q = 0; q < kBatch; q++) {
+                    const uint32_t i = min(i0 + q * kBlock, A_pad * nb - 1u), ant = i / nb, b = b0 + (i - ant * nb);
+                    kp[q] = *reinterpret_cast<const floatx2 *>(a.terms + 2u * ((uint64_t)min(ant, a.A - 1u) * a.B + min(b, a.B - 1u)));
                 }
-            } else {
-                const uint32_t nj = (na + 3u) >> 2; // antennas past A hold W = 0 and S = 0
-                for (uint32_t j = 0; j < nj; j++) {
-                    acc_re = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[(size_t)j * 4u * WS], sr[j * 64u], acc_re, 0, 0, 0);
-                    acc_im = __builtin_amdgcn_mfma_f32_16x16x4f32(wi[(size_t)j * 4u * WS], si[j * 64u], acc_im, 0, 0, 0);
+#pragma unroll 1
+                for (uint32_t q = 0; q < kBatch; q++) {
+                    const uint32_t i = i0 + q * kBlock, ant = i / nb, bl = i - ant * nb;
+                    floatx2 t = kp[0];
+#pragma unroll
+                    for (uint32_t z = 1; z < kBatch; z++) t = (z == q) ? kp[z] : t; // kp[q] without indexing registers
+                    float re, im;
+                    gen(t.x, t.y, re, im);
+                    if (i < A_pad * nb) {
+                        const bool live = ant < a.A && b0 + bl < a.B;
+                        Wre[ant * WS + bl] = live ? re : 0.0f;
+                        Wim[ant * WS + bl] = live ? im : 0.0f;
+                    }
                 }
+            }
+        });
+        __syncthreads(); // the only barrier of the kernel
+    }
+    // A "stage" of this wave = (one of its 16-sample blocks, chunk of kKC antennas), block-major.  The (re, im)
+    // int8 pairs of stage s + 1 are requested one stage ahead.  Whole chunks (64 antennas) take a path without any
+    // per-operand mask or clamp: the vector ALU issues at most ~12 instructions per MFMA on a SIMD, across all its
+    // waves, and a version that masked every operand (3-4 VALU instructions each) ran at 45-55 % of the matrix rate
+    // with or without its loads and stores.
+    const uint32_t n_chunks = (a.A + kKC - 1u) / kKC;
+    const uint32_t n_blocks = tt1 > tt0 + slot ? (tt1 - tt0 - slot + TPR - 1u) / TPR : 0u; // this wave's sample blocks
+    const uint32_t n_stages = n_blocks * n_chunks;
+    const uint16_t *ant16 = reinterpret_cast<const uint16_t *>(a.ant);
+    uint32_t cur[NJ], nxt[NJ];
+    auto fetch = [&](uint32_t s, uint32_t (&dst)[NJ]) {
+        const uint32_t tt = tt0 + (s / n_chunks) * TPR + slot, a0 = (s % n_chunks) * kKC; // tt < tt1 by construction
+        const uint16_t *p0 = ant16 + ((uint64_t)c * a.nT16 + tt) * a.A * 16u + lm; // [c][tt][antenna 0][sample] of (re, im)
+        if (a0 + kKC <= a.A) { // wave-uniform
+            const uint16_t *p = p0 + (size_t)(a0 + lg) * 16u;
+#pragma unroll
+            for (uint32_t j = 0; j < NJ; j++) dst[j] = p[(size_t)j * 64u]; // one base address, immediate offsets
+        } else {
+            // the last, partial chunk: raw, from a clamped (always valid) antenna index, masked where it is consumed.
+            // (A select(cond, load, 0) here becomes a load under an exec mask that hipcc waits for on the spot.)
+#pragma unroll
+            for (uint32_t j = 0; j < NJ; j++) dst[j] = p0[(size_t)min(a0 + lg + 4u * j, a.A - 1u) * 16u];
+        }
+    };
+    floatx4 acc_re = {0.0f, 0.0f, 0.0f, 0.0f}, acc_im = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (n_stages) fetch(0, cur);
+    for (uint32_t s = 0; s < n_stages; s++) {
+        const uint32_t blk = s / n_chunks, chunk = s - blk * n_chunks, a0 = chunk * kKC;
+        if (s + 1 < n_stages) fetch(s + 1, nxt);
+        // ---- k-steps of 4 antennas: two fma chains (re, im) in antenna order
+        const float *wr = lds + (size_t)(a0 + lg) * WS + bt * 16u + lm;
+        const float *wi = wr + (size_t)A_pad * WS;
+        if (a0 + kKC <= a.A) {
+#pragma unroll
+            for (uint32_t j = 0; j < NJ; j++) {
+                acc_re = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[(size_t)j * 4u * WS], (float)(int8_t)(cur[j] & 0xffu), acc_re, 0, 0, 0);
+                acc_im = __builtin_amdgcn_mfma_f32_16x16x4f32(wi[(size_t)j * 4u * WS], (float)(int8_t)(cur[j] >> 8), acc_im, 0, 0, 0);
+            }
+        } else { // antennas past A: W = 0 (rows up to A_pad) and S masked to 0
+            const uint32_t nj = (a.A - a0 + 3u) >> 2;
+            for (uint32_t j = 0; j < nj; j++) {
+                uint32_t v = cur[0];
+#pragma unroll
+                for (uint32_t z = 1; z < NJ; z++) v = (z == j) ? cur[z] : v; // cur[j] without indexing registers
+                v &= 0u - (uint32_t)(a0 + lg + 4u * j < a.A);
+                acc_re = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[(size_t)j * 4u * WS], (float)(int8_t)(v & 0xffu), acc_re, 0, 0, 0);
+                acc_im = __builtin_amdgcn_mfma_f32_16x16x4f32(wi[(size_t)j * 4u * WS], (float)(int8_t)(v >> 8), acc_im, 0, 0, 0);
             }
         }
-        if (my_tt < tt1) {
+        if (chunk + 1 == n_chunks) { // the block's last chunk: store, start the next block's sums
             // lane l, register r: beam b0 + 16 bt + 4 (l >> 4) + r, sample l & 15
-            floatx2 *dst = reinterpret_cast<floatx2 *>(a.beams) + ((uint64_t)c * a.nT16 + my_tt) * a.B * 16u + lm;
+            floatx2 *dst = reinterpret_cast<floatx2 *>(a.beams) + ((uint64_t)c * a.nT16 + tt0 + blk * TPR + slot) * a.B * 16u + lm;
             const uint32_t bb = b0 + bt * 16u + lg * 4u;
 #pragma unroll
             for (int r = 0; r < 4; r++)
                 if (bb + r < a.B) dst[(uint64_t)(bb + r) * 16u] = floatx2{acc_re[r], acc_im[r]};
+            acc_re = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
+            acc_im = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
         }
+#pragma unroll
+        for (uint32_t j = 0; j < NJ; j++) cur[j] = nxt[j];
     }
 }
 
@@ -157,25 +186,29 @@ static size_t bacc_lds_bytes(int nbt, uint32_t A)
 {
     const uint32_t A_pad = (A + 3u) & ~3u;
     const uint32_t ws = 16u * (uint32_t)nbt + (nbt > 1 ? 16u : 0u);
-    return ((size_t)A_pad * ws * 2u + (size_t)(4 / nbt) * kKC * 16u * 2u) * sizeof(float);
+    return (size_t)A_pad * ws * 2u * sizeof(float);
 }
 
 hipError_t bf_launch_beamform_acc(const bf_bacc_args &a_in, hipStream_t stream)
 {
     bf_bacc_args a = a_in;
     if (a.A == 0 || a.B == 0 || a.C == 0 || a.nT16 == 0) return hipSuccess;
-    // beam tiles per workgroup: as many as the beams need and 64 KiB of LDS hold
+    // beam tiles per workgroup: as many as the beams need while LDS still admits 6 workgroups per CU (26 KiB each);
+    // one tile whatever it takes beyond (256 antennas: 32 KiB)
     int nbt = a.B > 32u ? 4 : (a.B > 16u ? 2 : 1);
-    while (nbt > 1 && bacc_lds_bytes(nbt, a.A) > 64u * 1024u) nbt >>= 1;
+    while (nbt > 1 && bacc_lds_bytes(nbt, a.A) > 26u * 1024u) nbt >>= 1;
     const size_t lds = bacc_lds_bytes(nbt, a.A);
     if (lds > 64u * 1024u) return hipErrorInvalidValue; // more than 256 antennas: not built
     a.n_bgroups = (a.B + 16u * (uint32_t)nbt - 1u) / (16u * (uint32_t)nbt);
     // 16-sample blocks per workgroup: all of them (W is generated once per workgroup), fewer while that leaves
-    // the chip under 512 workgroups; whole rounds of 4 / nbt blocks
+    // the chip under 4096 workgroups; whole rounds of 4 / nbt blocks
     const uint32_t tpr = 4u / (uint32_t)nbt;
+    // (at most 16 rounds: a CU holds ~5 workgroups, and a launch of only a few thousand long-lived workgroups ends
+    // with most of the chip idle behind the last ones -- 4096 workgroups of 64 rounds ran at 80 % of what 16384 of
+    // 16 rounds do)
     uint32_t tiles = (a.nT16 + tpr - 1u) / tpr * tpr;
-    if (tiles > 64u * tpr) tiles = 64u * tpr;
-    while (tiles > tpr && (uint64_t)a.C * a.n_bgroups * ((a.nT16 + tiles - 1u) / tiles) < 512u) tiles = ((tiles / tpr + 1u) / 2u) * tpr;
+    if (tiles > 16u * tpr) tiles = 16u * tpr;
+    while (tiles > tpr && (uint64_t)a.C * a.n_bgroups * ((a.nT16 + tiles - 1u) / tiles) < 4096u) tiles = ((tiles / tpr + 1u) / 2u) * tpr;
     a.tiles_per_wg = tiles;
     a.n_tgroups = (a.nT16 + tiles - 1u) / tiles;
     const uint64_t blocks = (uint64_t)a.C * a.n_bgroups * a.n_tgroups;

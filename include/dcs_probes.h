@@ -50,6 +50,13 @@ int dcs_probe_one_store(void *d_out, size_t bytes, int store_mode, int stores_pe
  * max | re^2 + im^2 - 1 | (inf if any NaN).  Synchronises `stream`. */
 int dcs_probe_reduce(const void *d_in, size_t bytes, uint64_t *checksum, float *max_modulus_dev, void *stream);
 
+/* fp32 matrix-core issue-rate probe: `blocks` workgroups of 4 waves, each wave `iters` x 16 MFMAs back to back on
+ * register operands.  which = 0: v_mfma_f32_16x16x4_f32, 2 accumulators; 1: 4 accumulators; 2: v_mfma_f32_32x32x2_f32,
+ * 2 accumulators; 3: 16x16x4 with an int8 -> fp32 conversion in front of every pair; 4: the beamformer's k-step (A operands from LDS,
+ * B operands converted).
+ * FLOP per launch = blocks * 4 * iters * 16 * (2048 or 4096). */
+int dcs_probe_mfma(int which, uint32_t blocks, uint32_t iters, float *d_out, void *stream);
+
 #pragma GCC visibility pop
 #ifdef __cplusplus
 }

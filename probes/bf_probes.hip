@@ -284,9 +284,83 @@ hipError_t bf_launch_probe_one_store(void *out, size_t bytes, int store_mode_in,
     return hipGetLastError();
 }
 
+// fp32 matrix-core issue-rate probe: every wave runs `iters` x 16 MFMAs back to back on register operands
+// (which = 0: v_mfma_f32_16x16x4_f32 with 2 accumulators, 1: the same with 4, 2: v_mfma_f32_32x32x2_f32 with 2;
+//  3: 16x16x4 with a v_cvt between the MFMAs, as the coefficient-reuse beamformer has it).
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+template <int WHICH>
+__global__ void __launch_bounds__(kBlock) bf_probe_mfma_kernel(float *out, uint32_t iters, float seed)
+{
+    const float a0 = seed + (float)threadIdx.x * 0.001f, b0 = 1.0f - (float)(threadIdx.x & 7u) * 0.01f;
+    float acc_sum = 0.0f;
+    if constexpr (WHICH == 2) {
+        floatx16 c0 = {0}, c1 = {0};
+        for (uint32_t i = 0; i < iters; i++) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0 + (float)j, b0, c0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(b0, a0 + (float)j, c1, 0, 0, 0);
+            }
+        }
+        acc_sum = c0[0] + c1[3];
+    } else {
+        floatx4 c0 = {0, 0, 0, 0}, c1 = {0, 0, 0, 0}, c2 = {0, 0, 0, 0}, c3 = {0, 0, 0, 0};
+        uint32_t v = threadIdx.x * 2654435761u;
+        __shared__ float s_w[2 * 64 * 16];
+        if constexpr (WHICH == 4) {
+            for (uint32_t i = threadIdx.x; i < 2 * 64 * 16; i += kBlock) s_w[i] = seed + 0.001f * (float)i;
+            __syncthreads();
+        }
+        for (uint32_t i = 0; i < iters; i++) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                float b = b0;
+                if constexpr (WHICH == 4) { // both A operands from LDS, B converted: the beamformer's k-step
+                    b = (float)(int8_t)(v & 0xffu);
+                    const float bi = (float)(int8_t)((v >> 8) & 0xffu);
+                    v = (v >> 16) | (v << 16);
+                    const float wr = s_w[(threadIdx.x & 63u) + 64 * (2 * j)], wi = s_w[(threadIdx.x & 63u) + 64 * (2 * j + 1)];
+                    c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wr, b, c0, 0, 0, 0);
+                    c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wi, bi, c1, 0, 0, 0);
+                    continue;
+                }
+                if constexpr (WHICH == 3) {
+                    b = (float)(int8_t)(v & 0xffu);
+                    v = (v >> 8) | (v << 24);
+                }
+                if (WHICH == 1 && (j & 1)) {
+                    c2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0 + (float)j, b, c2, 0, 0, 0);
+                    c3 = __builtin_amdgcn_mfma_f32_16x16x4f32(b, a0, c3, 0, 0, 0);
+                } else {
+                    c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0 + (float)j, b, c0, 0, 0, 0);
+                    c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(b, a0, c1, 0, 0, 0);
+                }
+            }
+        }
+        acc_sum = c0[0] + c1[1] + c2[2] + c3[3];
+    }
+    if (acc_sum == 12345.678f) out[blockIdx.x] = acc_sum; // keep the chain alive
+}
+
 } // namespace
 
 extern "C" {
+
+// MFMA issue-rate probe: grid x 4 waves, each `iters` x 16 MFMAs (which: see bf_probe_mfma_kernel).
+int dcs_probe_mfma(int which, uint32_t blocks, uint32_t iters, float *d_out, void *stream)
+{
+    if (which < 0 || which > 4 || !d_out || blocks == 0) return DCS_ERR_INVALID_ARGUMENT;
+    const dim3 grid(blocks), block(kBlock);
+    switch (which) {
+    case 0: hipLaunchKernelGGL(bf_probe_mfma_kernel<0>, grid, block, 0, as_stream(stream), d_out, iters, 1.0f); break;
+    case 1: hipLaunchKernelGGL(bf_probe_mfma_kernel<1>, grid, block, 0, as_stream(stream), d_out, iters, 1.0f); break;
+    case 2: hipLaunchKernelGGL(bf_probe_mfma_kernel<2>, grid, block, 0, as_stream(stream), d_out, iters, 1.0f); break;
+    case 3: hipLaunchKernelGGL(bf_probe_mfma_kernel<3>, grid, block, 0, as_stream(stream), d_out, iters, 1.0f); break;
+    default: hipLaunchKernelGGL(bf_probe_mfma_kernel<4>, grid, block, 0, as_stream(stream), d_out, iters, 1.0f); break;
+    }
+    return (int)hipGetLastError();
+}
+
 
 int dcs_probe_sincos(int which, const float *d_x, size_t n, float *d_sin, float *d_cos, void *stream)
 {

@@ -20,6 +20,7 @@ SIGNATURES = [
     ("dcs_probe_fill", c_int, [_VP, c_size_t, c_int, _VP]),
     ("dcs_probe_one_store", c_int, [_VP, c_size_t, c_int, c_int, c_uint32, _VP]),
     ("dcs_probe_reduce", c_int, [_VP, c_size_t, POINTER(c_uint64), POINTER(c_float), _VP]),
+    ("dcs_probe_mfma", c_int, [c_int, c_uint32, c_uint32, _VP, _VP]),
     ("dcs_probe_store_pattern", c_int, [_VP, c_uint32, c_uint32, c_uint32, c_uint32, c_int, c_int, c_int, c_uint32, _VP]),
 ]
 
@@ -76,3 +77,7 @@ def store_pattern(d_out, rows, cols_kib, qb, rb, order=0, xcd_remap=0, store_mod
 def one_store(d_out, nbytes, store_mode, stores_per_thread, row_bytes, stream=None) -> None:
     _check(lib().dcs_probe_one_store(c_void_p(int(d_out)), int(nbytes), int(store_mode), int(stores_per_thread), int(row_bytes),
                                      _s(stream)), "dcs_probe_one_store")
+
+
+def mfma(which: int, blocks: int, iters: int, d_out, stream=None) -> None:
+    _check(lib().dcs_probe_mfma(int(which), int(blocks), int(iters), c_void_p(int(d_out)), _s(stream)), "dcs_probe_mfma")

@@ -213,8 +213,11 @@ def cmd_fused(args):
 def cmd_bfacc(args):
     """Beamformer with coefficient reuse on the matrix cores: rate against its roofline (int8 samples in + fp32 beams
     out vs 8 TB/s; fp32 MFMA 2 * 2 * A * B flop per sample vs 155 TFLOP/s)."""
-    for (A, B, C, nt) in ((64, 16, 64, 256), (64, 16, 4096, 256), (64, 16, 4096, 4096), (64, 64, 4096, 256), (64, 256, 1024, 256), (256, 64, 1024, 256),
-                          (64, 1024, 256, 256)):
+    shapes = ((64, 16, 64, 256), (64, 16, 4096, 256), (64, 16, 4096, 4096), (64, 64, 4096, 256), (64, 256, 1024, 256), (256, 64, 1024, 256),
+              (64, 1024, 256, 256))
+    if args.shape:
+        shapes = (tuple(int(v) for v in args.shape.split("x")),)
+    for (A, B, C, nt) in shapes:
         bp = BeamformerParameters(NR_CHANNELS=C, NR_STATIONS=A, NR_BEAMS=B, NR_SAMPLES_PER_CHANNEL=nt)
         g = SteeringCoefficientGenerator(bp)
         g.upload_delays(simulate_input(bp))
@@ -229,6 +232,21 @@ def cmd_bfacc(args):
         g.close()
         d_ant.free()
         d_beams.free()
+
+
+def cmd_mfma(args):
+    """fp32 matrix-core issue rate on register operands (what the coefficient-reuse beamformer is measured against)."""
+    from probes import dcs_probes as pr
+
+    out = device.mem_alloc(1 << 20)
+    for which, name, flop in ((0, "v_mfma_f32_16x16x4_f32, 2 accumulators", 2048), (1, "v_mfma_f32_16x16x4_f32, 4 accumulators", 2048),
+                              (2, "v_mfma_f32_32x32x2_f32, 2 accumulators", 4096), (3, "16x16x4 with int8->fp32 conversions between", 2048),
+                              (4, "16x16x4, A operands from LDS + conversions (the beamformer k-step)", 2048)):
+        for blocks in (256, 512, 1024, 2048):
+            iters = 4096
+            ms = min(per_launch_ms(lambda: pr.mfma(which, blocks, iters, out), settle_ms=20, timed_ms=20) for _ in range(2))
+            n = blocks * 4 * iters * (16 if which != 2 else 8)
+            print(f"{name}, {blocks} workgroups ({blocks * 4 / 1024:.0f} waves per SIMD): {n * flop / ms / 1e9:.1f} TFLOP/s", flush=True)
 
 
 def cmd_stream(args):
@@ -396,7 +414,9 @@ def main():
     p.add_argument("--form", type=int, default=1, help="1 = per-workgroup terms, 3 = terms table, 0 = library's choice")
     p.add_argument("--bits", type=int, default=16, choices=[16, 32])
     sub.add_parser("fused")
-    sub.add_parser("bfacc")
+    sub.add_parser("mfma")
+    p = sub.add_parser("bfacc")
+    p.add_argument("--shape", default="", help="AxBxCxNT: one shape only (PMC passes)")
     p = sub.add_parser("stream")
     p.add_argument("--model-step-us", type=float, default=200.0)
     sub.add_parser("pmc")
@@ -419,7 +439,7 @@ def main():
     device.require_device()
     device.set_device(0)
     print("device:", device.device_name(0), flush=True)
-    {"geometry": cmd_geometry, "refshape": cmd_refshape, "fp16": cmd_fp16, "fused": cmd_fused, "bfacc": cmd_bfacc, "stream": cmd_stream, "pmc": cmd_pmc,
+    {"geometry": cmd_geometry, "refshape": cmd_refshape, "fp16": cmd_fp16, "fused": cmd_fused, "mfma": cmd_mfma, "bfacc": cmd_bfacc, "stream": cmd_stream, "pmc": cmd_pmc,
      "sustained": cmd_sustained, "stores": cmd_stores, "sincos": cmd_sincos}[args.cmd](args)
 
 
