@@ -91,14 +91,14 @@ geometry {b['config']['launch_geometry']}: {vg['VGPR_Count']} VGPRs, {vg['LDS_Bl
 | same, 10 warm-up + 50 timed launches | {st.mean(d):.4f} ms |
 | rocprofv3 `--stats` AverageNs of the production kernel symbol, all {len(allms)} calls (untimed settle launches + 10 warm-up + 50 timed) | {st.mean(allms):.4f} ms |
 | WRITE_SIZE per launch | {res['WRITE_SIZE'][1]:.0f} KiB x 1024 = {w / 1e9:.4f} GB = {w / algo:.5f} x algorithmic ({algo / 1e9:.4f} GB) |
-| FETCH_SIZE per launch | {res['FETCH_SIZE'][1]:.0f} KiB x 1024 x 2 (gfx950 correction) = {fr / 1e6:.2f} MB (the 1 MiB delay table) |
+| FETCH_SIZE per launch | {res['FETCH_SIZE'][1]:.0f} KiB x 1024 x 2 (gfx950 correction) = {fr / 1e6:.2f} MB (the pre-pass reads the 1 MiB delay table; the main kernel its 512 KiB terms table) |
 | CPU baseline in the same bench run (oracle = restated reference verifier) | {cb.get('value', 0) * 1e3:.1f} Mcoeff/s on 1 thread ({cb.get('sample', '')}); {cb.get('all_cores', {}).get('value', 0):.2f} Gcoeff/s on {cb.get('all_cores', {}).get('cores', 0)} threads |
 
 bench.py first lets the library measure its launch geometry (untimed; separate kernel symbols), then runs 24 plain fills of the output buffer
 (`__amd_rocclr_fillBufferAligned`, ~2.8 ms each = 6.1 TB/s) to bring the device out of idle; the first few generator launches are
 still 3-10 % slower than steady state and fall in the W = 10 warm-up steps.  The event-based `kernel_ms`, the per-dispatch
 trace of the same launches and the `--stats` average agree within 1 % (the event span also holds the 5-us slice gather and the gaps between launches, which grow a little under the profiler).  HBM traffic equals the algorithmic bytes: every store is a whole-line write,
-nothing is re-read.  Box-to-box spread seen this round: 870-925 Gcoeff/s.
+nothing is re-read.  Box-to-box spread seen this round: 915-930 Gcoeff/s (five boxes).
 """
 open(R + f"profiles/{rnd}_bench_profile.md", "w").write(md)
 print(md[md.index("| quantity"):])
