@@ -5,37 +5,42 @@
 // (calculate_beamweights_and_beamform_single_channel, BeamformerKernels.cu:192-367) and only MODELS
 // what a deployed beamformer does: new coefficients every ACCUMULATIONS_BEFORE_NEW_COEFFS time units
 // (BeamformerParameters.h:17; BeamformerCoefficientTest.cu:426-448).  Here the coefficients of ONE time
-// are generated once per (channel, antenna, beam) -- into LDS, never HBM -- and applied to a block of
-// samples:
+// are generated once per (channel, antenna, beam) -- into registers or LDS, never HBM -- and applied to a
+// block of samples:
 //   beams[c][t/16][b][t%16] = ( sum_a cos(rot[a][b][c]) * re[c][t][a] ,  sum_a sin(rot[a][b][c]) * im[c][t][a] )
 // (the reference's element-wise product, BeamformerKernels.cu:315-316; table indexed [b*A + a]; layouts
 // BeamformerKernels.cuh:137-143).  Per channel that is two real contractions over antennas,
-//   Re[beam][t] = Wre[beam][ant] x Sre[ant][t]      Im likewise,
-// run on v_mfma_f32_16x16x4_f32: exact-fp32 products, accumulated as an fp32 fma chain IN ANTENNA ORDER
-// (the instruction is, bit for bit, a k-ordered fmaf chain), so the result differs from the verifier's
-// "sum += coeff * sample" (separate multiply and add) by the roundings of the chain only.
+//   Re[beam][t] = Wre[beam][ant] x Sre[ant][t]      Im likewise.
+// Roofline: int8 samples in (2 B per antenna and sample) + fp32 beams out (8 B per beam and sample) against HBM.
 //
-// Workgroup = 4 waves = one channel x NBT beam tiles of 16 x a range of 16-sample blocks:
-//   wave w: beam tile w % NBT, sample-block slot w / NBT of each round (4 / NBT blocks per round).
-// The waves never wait for each other in the sample loop: a lane reads the (re, im) int8 pair of its own
-// B operand straight from global memory (one 2-byte load per k-step; a wave's 64 lanes cover one 128-byte
-// line, which the waves of the other beam tiles then find in L1), one stage ahead of the matrix pipe, and
-// converts it on the VALU, which idles otherwise.  W (all antennas x 16*NBT beams, re and im planes) is generated
-// once per workgroup into LDS from the terms table bf_bform_terms_kernel writes ([a][b]; L2-resident) -- the
-// kernel's only barrier -- and read from there, one ds_read_b32 per A operand (a quarter of the LDS bandwidth at
-// the full matrix rate).  Few registers, so that 6-8 waves per SIMD hide the memory latencies: loads AND stores
-// take 2-3 thousand cycles under this load, three times a wave's matrix phase; versions that held W in registers
-// (106-138 VGPRs, 3-4 waves per SIMD) or staged samples through LDS behind barriers all stalled at 45 %.  (Two earlier versions staged
-// the samples through LDS -- as fp32 planes, then as int8 -- behind two barriers per round: 45 % of the matrix
-// rate, bound first by LDS bandwidth, then by the waves waiting for each other.)
-//   A operand, lane l: W[beam l & 15][antenna 4j + (l >> 4)]   B operand: S[antenna 4j + (l >> 4)][sample l & 15]
-// C/D: lane l, register r = beam (l >> 4) * 4 + r, sample l & 15.
-// Roofline: int8 samples in (2 B per antenna and sample) + fp32 beams out (8 B per beam and sample) against
-// HBM; the fp32 matrix rate (64 FLOP / clk / SIMD) bounds it from ~32 beams per 64 antennas upwards.
+// Two forms (bf_bacc_args.fp32_chain):
+//
+// 1. bf_beamform_i8_kernel (default; second half of this file): the contraction in EXACT integer arithmetic on
+//    v_mfma_i32_16x16x64_i8 -- 24-bit fixed-point coefficients as three signed digits -- which takes the matrix
+//    work out of the picture (32 x the fp32 pipe's rate) and leaves a kernel bound by the memory system:
+//    at 16 beams (as many bytes in as out) 5.0-5.7 TB/s, 80-90 % of what the leanest device copy kernel moves on
+//    the same box (6.3 TB/s) and more than hipMemcpyDtoD (5.0); at >= 64 beams (output-dominated) 4.7-4.9 TB/s, the
+//    rate this chip gives long-lived waves that each stream 64 stores (profiles/r01_store_patterns.md: 5.4-5.5).
+//
+// 2. bf_beamform_acc_kernel (first half): v_mfma_f32_16x16x4_f32, exact-fp32 products accumulated as an fp32 fma
+//    chain IN ANTENNA ORDER (the instruction is, bit for bit, a k-ordered fmaf chain), so the result differs from
+//    the verifier's "sum += coeff * sample" (separate multiply and add) by the roundings of the chain only.
+//    Workgroup = 4 waves = one channel x NBT beam tiles of 16 x a range of 16-sample blocks:
+//      wave w: beam tile w % NBT, sample-block slot w / NBT of each round (4 / NBT blocks per round).
+//    A lane reads the (re, im) int8 pair of its own B operand straight from global memory (one 2-byte load per
+//    k-step), one stage ahead of the matrix pipe, and converts it on the VALU.  W (all antennas x 16*NBT beams,
+//    re and im planes) is generated once per workgroup into LDS from the terms table bf_bform_terms_kernel
+//    writes ([a][b]; L2-resident) -- the kernel's only barrier -- and read from there, one ds_read_b32 per A
+//    operand.  0.38-0.53 of the fp32 matrix peak across six structures (profiles/r02_fused.md); kept as the form
+//    whose rounding is the verifier's loop with fused multiply-adds.
+//      A operand, lane l: W[beam l & 15][antenna 4j + (l >> 4)]   B operand: S[antenna 4j + (l >> 4)][sample l & 15]
+//    C/D: lane l, register r = beam (l >> 4) * 4 + r, sample l & 15.
 
 #include "bf_kernels.h"
 
 #include <hip/hip_runtime.h>
+
+#include <type_traits>
 
 #include "bf_device.h"
 
@@ -179,6 +184,408 @@ __global__ void __launch_bounds__(kBlock) bf_beamform_acc_kernel(const bf_bacc_a
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// The same contraction on the int8 matrix pipe (v_mfma_i32_16x16x64_i8, 32x the fp32 pipe's rate), EXACTLY:
+// the samples ARE int8, and a coefficient w in [-1, 1] is taken as the 24-bit fixed-point number
+//   F = rint(w * 8355711) = d1 * 65536 + d2 * 256 + d3,   d1, d2, d3 in [-128, 127]   (8355711 = 0x7F7F7F),
+// so that  sum_a w_a x_a  ~=  (65536 * sum d1 x  +  256 * sum d2 x  +  sum d3 x) / 8355711:  three integer
+// contractions per plane and 64 antennas whose sums are exact (|sum| <= 128 * 128 * 64 = 2^20) -- no rounding
+// depends on the order of the antennas; the two low sums are combined in integers, and that and the high sum (and
+// the chunks of more than 64 antennas) are scaled by exact powers of two and added in fp32.  What differs from the
+// verifier's fp32 "sum += coeff * sample" is the quantisation of each coefficient (|F / 8355711 - w| <=
+// 0.75 / 8355711 = 9e-8: the size of the fp32 coefficient's own last place) and the verifier's OWN accumulation
+// roundings; against an exact-arithmetic sum of the fp32 coefficients the result is within 9e-8 * sum_a |x_a| + a
+// few ulp (tests/test_gpu_parity.py holds it to that).
+//
+// A wave owns one 16-beam tile of one channel and some of the workgroup's 16-sample blocks.  Its coefficients
+// (64 antennas = 6 operands of 4 registers: 3 digits x {re, im}) are made once, in registers (waves that own the
+// same tile make a share each and exchange them through LDS).  Up to 64 antennas the workgroup's sample blocks
+// (at most 16 = 32 KiB) travel to LDS by LDS-DMA while the coefficients are being made; beyond, a wave loads its
+// operands itself, two load sets in flight.  Per pair of blocks and 64 antennas: 16 four-byte operand reads per
+// lane, a 4 x 4 byte transpose into four K = 64 operands (slot (lane >> 4, byte p) of BOTH operands is antenna
+// 64 ch + 4 p + (lane >> 4): the contraction index may be permuted freely as long as both sides agree), 12 MFMAs,
+// ~130 vector instructions to recombine, 4 sixteen-byte stores.  The arithmetic is hidden entirely: with its stores
+// alone, no loads and no coefficients, the kernel is as fast (profiles/r02_fused.md).
+typedef int intx4 __attribute__((ext_vector_type(4)));
+constexpr float kFixScale = 8355711.0f;
+
+// The three signed digits of rint(w * 8355711), one per byte (byte 0 = d3 ... byte 2 = d1; byte 3 unused): with every
+// digit biased by 128 the number F + 0x808080 is a plain 24-bit unsigned whose bytes are d + 128, and (d + 128) ^ 0x80
+// is d as a signed byte -- no borrows to chase.
+__device__ __forceinline__ uint32_t fixed_word(float w)
+{
+    // a coefficient one ulp above 1 must not carry into a fourth digit
+    const float f = __builtin_amdgcn_fmed3f(w * kFixScale, -kFixScale, kFixScale);
+    return ((uint32_t)(int)rintf(f) + 0x808080u) ^ 0x808080u;
+}
+
+// NCH = 1, 2 or 4 chunks of 64 antennas; FULL: nr_stations == 64 * NCH; STAGED (NCH == 1): the workgroup's sample blocks
+// (at most 16: 32 KiB) travel to LDS by LDS-DMA, all at once and while the coefficients are being made, and the waves
+// read their operands from there -- every wave of the workgroup needs the same blocks when it owns several beam tiles,
+// and no wave ever waits for a global load inside its loop (a wave that loads its own operands pays one memory
+// latency per trip; with loads and stores but no arithmetic that form ran exactly as fast as with the arithmetic).
+template <int NCH, bool FULL, bool STAGED>
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(NCH == 1 ? (FULL ? 4 : 3) : (NCH == 2 ? 2 : 1))))
+bf_beamform_i8_kernel(const bf_bacc_args a)
+{
+    static_assert(!STAGED || NCH == 1, "the staged form holds one 64-antenna chunk");
+    extern __shared__ __attribute__((aligned(16))) char staged[];
+    uint32_t bid = blockIdx.x;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t bg = bid % a.n_bgroups;
+    bid /= a.n_bgroups;
+    const uint32_t tg = bid % a.n_tgroups;
+    const uint32_t c = bid / a.n_tgroups;
+    const uint32_t nbt = 1u << a.nbt_log2, tpr = 4u >> a.nbt_log2; // beam tiles per workgroup, sample blocks per round
+    const uint32_t bt = wave & (nbt - 1u), slot = wave >> a.nbt_log2;
+    const uint32_t lm = lane & 15u, lg = lane >> 4;
+    const uint32_t bw = (bg * nbt + bt) * 16u;     // first beam of this wave's tile
+    const uint32_t tt0 = tg * a.tiles_per_wg;      // first 16-sample block of the workgroup
+    const uint32_t tt1 = min(tt0 + a.tiles_per_wg, a.nT16);
+    const uint32_t n_blocks = tt1 > tt0 + slot ? (tt1 - tt0 - slot + tpr - 1u) / tpr : 0u; // this wave's sample blocks
+    const bool idle = bw >= a.B || n_blocks == 0u; // wave-uniform
+    if (!STAGED && idle) return;                   // (no barrier in the unstaged form)
+    if (STAGED) { // this wave's share of the workgroup's blocks: global -> LDS, 1 KiB per instruction, same byte order
+        typedef __attribute__((address_space(3))) void lds_void;
+        typedef const __attribute__((address_space(1))) void glb_void;
+        const uint32_t bytes = (tt1 - tt0) * a.A * 32u; // a multiple of 32
+        const char *src = reinterpret_cast<const char *>(a.ant) + ((uint64_t)c * a.nT16 + tt0) * a.A * 32u;
+        for (uint32_t k = wave; k * 1024u < bytes; k += 4u) // a piece that overhangs the end re-reads the last 16 bytes
+            __builtin_amdgcn_global_load_lds((glb_void *)(src + min(k * 1024u + lane * 16u, bytes - 16u)), (lds_void *)(staged + k * 1024u),
+                                             16, 0, 0);
+    }
+
+    const uint32_t cls = a.flags[0];
+    const float fChan = (float)c;
+    const float D = a.k.fDenominator, y = a.k.fRcpDenominator;
+
+    // ---- coefficients: lane (beam lm, group lg) holds, in byte p of operand (ch, digit), antenna 64 ch + 4 p + lg.
+    //      Per chunk: 16 terms loads in flight together, then four rolled trips of four antennas each: a trip makes one
+    //      whole register of each of the six operands, which enters at the top while the others move down (after four
+    //      trips register q holds antennas 4 (4 q .. 4 q + 3) + lg), and the loaded terms move down by four likewise --
+    //      no register is ever indexed by a loop variable.
+    // STAGED, fewer than four beam tiles per workgroup: the 4 / nbt waves that own the same tile make a quarter (half)
+    // of its coefficient registers each and exchange them through LDS behind the staging barrier (the slow class makes
+    // everything everywhere: its rolled loop does not split)
+    const bool shared_w = STAGED && a.share_off != 0u && tpr > 1u && cls != DCS_CLASS_SLOW;
+    intx4 wre[NCH][3], wim[NCH][3];
+#pragma unroll
+    for (int ch = 0; ch < NCH; ch++)
+#pragma unroll
+        for (int d = 0; d < 3; d++) wre[ch][d] = wim[ch][d] = intx4{0, 0, 0, 0};
+    auto make_coefficients = [&](intx4 (&wre)[NCH][3], intx4 (&wim)[NCH][3]) {
+        // row i of the result tile is beam 4 (i & 3) + (i >> 2): the four lane groups of a store instruction then
+        // hold four CONSECUTIVE beams (512 contiguous bytes per block) instead of every fourth
+        const uint32_t beam = bw + 4u * (lm & 3u) + (lm >> 2);
+        const bool beam_live = beam < a.B;
+        const float *tp = a.terms + 2u * (uint64_t)min(beam, a.B - 1u);
+        // four antennas' words -> one register of each digit plane (a 4 x 4 byte transpose; byte z = antenna z)
+        auto planes = [](const uint32_t (&g)[4], uint32_t (&out)[3]) {
+            const uint32_t t0 = __builtin_amdgcn_perm(g[1], g[0], 0x05010400u), t1 = __builtin_amdgcn_perm(g[1], g[0], 0x07030602u);
+            const uint32_t t2 = __builtin_amdgcn_perm(g[3], g[2], 0x05010400u), t3 = __builtin_amdgcn_perm(g[3], g[2], 0x07030602u);
+            out[2] = __builtin_amdgcn_perm(t2, t0, 0x05040100u); // bytes 0: d3
+            out[1] = __builtin_amdgcn_perm(t2, t0, 0x07060302u); // bytes 1: d2
+            out[0] = __builtin_amdgcn_perm(t3, t1, 0x05040100u); // bytes 2: d1
+        };
+        // antennas 4 (4 q + z) + lg, z = 0..3, of chunk ch from their terms: one register of each of the six operands
+        auto four = [&](auto gen, int ch, uint32_t q, const floatx2 (&k4)[4], uint32_t (&nr)[3], uint32_t (&ni)[3]) {
+            uint32_t gr[4], gi[4];
+#pragma unroll
+            for (uint32_t z = 0; z < 4; z++) {
+                float re, im;
+                gen(k4[z].x, k4[z].y, re, im);
+                gr[z] = fixed_word(re), gi[z] = fixed_word(im);
+            }
+            planes(gr, nr), planes(gi, ni);
+            if (!FULL) { // antennas beyond nr_stations: zero digits, byte by byte
+                uint32_t mask = 0;
+#pragma unroll
+                for (uint32_t z = 0; z < 4; z++) mask |= 64u * ch + 4u * (4u * q + z) + lg < a.A ? 0xffu << (8u * z) : 0u;
+#pragma unroll
+                for (int d = 0; d < 3; d++) nr[d] &= mask, ni[d] &= mask;
+            }
+        };
+        auto generate = [&](auto gen, auto unrolled) {
+#pragma unroll
+            for (int ch = 0; ch < NCH; ch++) {
+                floatx2 kp[16];
+#pragma unroll
+                for (uint32_t z = 0; z < 16; z++) {
+                    const uint32_t ant = 64u * ch + 4u * z + lg;
+                    kp[z] = *reinterpret_cast<const floatx2 *>(tp + 2u * (uint64_t)min(ant, a.A - 1u) * a.B);
+                }
+                if (decltype(unrolled)::value) { // the fast classes: 16 copies of ~34 instructions, nothing moves
+#pragma unroll
+                    for (uint32_t q = 0; q < 4; q++) {
+                        if (shared_w && (q & (tpr - 1u)) != slot) continue; // a wave sharing its tile makes its own registers only
+                        const floatx2 k4[4] = {kp[4 * q], kp[4 * q + 1], kp[4 * q + 2], kp[4 * q + 3]};
+                        uint32_t nr[3], ni[3];
+                        four(gen, ch, q, k4, nr, ni);
+#pragma unroll
+                        for (int d = 0; d < 3; d++) wre[ch][d][q] = (int)nr[d], wim[ch][d][q] = (int)ni[d];
+                    }
+                } else { // the slow class (fp64 sincos): four rolled trips; the new register enters at the top while the
+                         // others, and the loaded terms, move down -- no register is indexed by a loop variable
+#pragma unroll
+                    for (int d = 0; d < 3; d++) wre[ch][d] = intx4{0, 0, 0, 0}, wim[ch][d] = intx4{0, 0, 0, 0};
+#pragma unroll 1
+                    for (uint32_t q = 0; q < 4; q++) {
+                        const floatx2 k4[4] = {kp[0], kp[1], kp[2], kp[3]};
+                        uint32_t nr[3], ni[3];
+                        four(gen, ch, q, k4, nr, ni);
+#pragma unroll
+                        for (int d = 0; d < 3; d++) {
+                            wre[ch][d] = intx4{wre[ch][d][1], wre[ch][d][2], wre[ch][d][3], (int)nr[d]};
+                            wim[ch][d] = intx4{wim[ch][d][1], wim[ch][d][2], wim[ch][d][3], (int)ni[d]};
+                        }
+#pragma unroll
+                        for (uint32_t z = 0; z < 12; z++) kp[z] = kp[z + 4];
+                    }
+                }
+                if (!beam_live) { // beams beyond nr_beams: zero coefficients (their results are not stored either)
+#pragma unroll
+                    for (int d = 0; d < 3; d++) wre[ch][d] = intx4{0, 0, 0, 0}, wim[ch][d] = intx4{0, 0, 0, 0};
+                }
+                __builtin_amdgcn_sched_barrier(0); // one chunk's 16 terms loads (32 registers) at a time
+            }
+        };
+        if (cls == DCS_CLASS_SLOW) {
+            generate([&](float kx, float ky, float &re, float &im) { coeff_slow(kx, ky, fChan, D, re, im); }, std::false_type{});
+        } else {
+            dispatch_fast(a.k.uDiv3Exact != 0u, cls == DCS_CLASS_FAST_LOW, [&](auto div3, auto lowdeg) {
+                generate([&](float kx, float ky, float &re, float &im) {
+                    coeff_fast<decltype(div3)::value, decltype(lowdeg)::value>(kx, ky, fChan, D, y, re, im);
+                }, std::true_type{});
+            });
+        }
+    };
+
+    // ---- sample blocks, two at a time.  Column n of the B operand is NOT "sample n of one block": a lane loads the
+    //      4 bytes {re, im} x samples (2 m, 2 m + 1), m = n & 7, of block A (n < 8) or block B (n >= 8) of its pair, so
+    //      one 4-byte load per antenna serves FOUR contractions -- (even samples, odd samples) x (re, im) -- whose
+    //      16 columns are 8 sample pairs of block A and 8 of block B.  A 4 x 4 byte transpose (8 v_perm_b32 per 4
+    //      antennas) turns 16 loaded registers into the 4 K = 64 operands; a result lane holds samples 2 m and 2 m + 1 of
+    //      its 4 beams: one 16-byte store each.  Half the load and store instructions of a per-block scheme and no
+    //      half-word merging (d16 loads do not keep the other half with SRAM-ECC on).
+    //      Addresses: a wave-uniform base (scalar registers) plus a per-lane byte offset; with whole chunks (FULL) ONE
+    //      offset register and the instruction's immediate (antenna 4 p + lg is 128 p bytes further), otherwise offsets
+    //      clamped to the last antenna (the coefficient digits are 0 beyond nr_stations).
+    //      Two load sets (pairs, or chunks of one pair) are in flight per wave.  hipcc waits for ALL memory operations
+    //      at the head of a loop whose loads cross the back-edge, stores included, so the order inside a trip is: wait,
+    //      transpose, MFMAs, STORES, then the next trip's LOADS -- one memory latency per trip, shared by loads and
+    //      stores (with the loads issued first, each trip paid the load and the store latency one after the other:
+    //      3.2 us per block and wave, 40-60 % of the HBM rate; a block's arithmetic is ~0.2 us).
+    const char *ant8 = reinterpret_cast<const char *>(a.ant);
+    const uint32_t blk_bytes = a.A * 32u;            // one 16-sample block of one channel: <= 8 KiB
+    const uint32_t m = lm & 7u;
+    const bool second = lm >= 8u;                    // this lane's columns belong to block B of the pair
+    const uint32_t last = n_blocks - 1u;
+    const uint32_t voff = lg * 32u + m * 4u;
+    uint32_t cur[2][16];
+    // "every loaded register is needed HERE": keeps the compiler from sinking a load set into the trip that consumes it
+    auto arrived = [&](uint32_t (&v)[16]) {
+        asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]));
+        asm volatile("" : "+v"(v[8]), "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15]));
+    };
+    auto fetch = [&](uint32_t (&dst)[16], uint32_t blk, uint32_t ch) { // pair (blk, min(blk + 1, last)), chunk ch
+        const uint32_t blkA = min(blk, last), blkB = min(blk + 1u, last);
+        if (STAGED) { // from the LDS image: block j of the workgroup at j * blk_bytes
+            const uint32_t at = ((second ? blkB : blkA) * tpr + slot) * blk_bytes + m * 4u;
+#pragma unroll
+            for (uint32_t p = 0; p < 16; p++)
+                dst[p] = *reinterpret_cast<const uint32_t *>(staged + at + (FULL ? lg + 4u * p : min(lg + 4u * p, a.A - 1u)) * 32u);
+            return;
+        }
+        const char *base = ant8 + ((uint64_t)c * a.nT16 + tt0 + blkA * tpr + slot) * blk_bytes; // wave-uniform
+        const uint32_t hop = second ? (blkB - blkA) * tpr * blk_bytes : 0u;
+        if (FULL) {
+            const char *b2 = base + 2048u * ch;
+            const uint32_t vo = hop + voff;
+#pragma unroll
+            for (uint32_t p = 0; p < 16; p++) dst[p] = *reinterpret_cast<const uint32_t *>(b2 + vo + 128u * p);
+        } else {
+#pragma unroll
+            for (uint32_t p = 0; p < 16; p++)
+                dst[p] = *reinterpret_cast<const uint32_t *>(base + (hop + min(64u * ch + lg + 4u * p, a.A - 1u) * 32u + m * 4u));
+        }
+    };
+    // x[0] = re of the even samples, x[1] = im even, x[2] = re odd, x[3] = im odd; byte p of each = antenna 4 p + lg
+    auto transpose = [&](const uint32_t (&v)[16], intx4 (&x)[4]) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const uint32_t t0 = __builtin_amdgcn_perm(v[4 * q + 1], v[4 * q], 0x05010400u);     // {a0.b0, a1.b0, a0.b1, a1.b1}
+            const uint32_t t1 = __builtin_amdgcn_perm(v[4 * q + 1], v[4 * q], 0x07030602u);     // {a0.b2, a1.b2, a0.b3, a1.b3}
+            const uint32_t t2 = __builtin_amdgcn_perm(v[4 * q + 3], v[4 * q + 2], 0x05010400u);
+            const uint32_t t3 = __builtin_amdgcn_perm(v[4 * q + 3], v[4 * q + 2], 0x07030602u);
+            x[0][q] = (int)__builtin_amdgcn_perm(t2, t0, 0x05040100u);
+            x[1][q] = (int)__builtin_amdgcn_perm(t2, t0, 0x07060302u);
+            x[2][q] = (int)__builtin_amdgcn_perm(t3, t1, 0x05040100u);
+            x[3][q] = (int)__builtin_amdgcn_perm(t3, t1, 0x07060302u);
+        }
+    };
+    // One load set (64 antennas of a pair of blocks) into the running fp32 sums f[v], plane v = (re even, im even,
+    // re odd, im odd): three integer contractions from zero per plane, each exact (|sum| < 2^21); the two low digits are
+    // combined in integers (s2 * 256 + s3 < 2^29: exact), converted (one rounding, far below the result's last place),
+    // and the high digit enters with one fma.
+    const intx4 zero = {0, 0, 0, 0};
+    auto contract = [&](int ch, const intx4 (&x)[4], floatx4 (&f)[4], bool first) {
+#pragma unroll
+        for (int v = 0; v < 4; v++) {
+            const intx4 s3 = __builtin_amdgcn_mfma_i32_16x16x64_i8((v & 1) ? wim[ch][2] : wre[ch][2], x[v], zero, 0, 0, 0);
+            const intx4 s2 = __builtin_amdgcn_mfma_i32_16x16x64_i8((v & 1) ? wim[ch][1] : wre[ch][1], x[v], zero, 0, 0, 0);
+            const intx4 s1 = __builtin_amdgcn_mfma_i32_16x16x64_i8((v & 1) ? wim[ch][0] : wre[ch][0], x[v], zero, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const float lo = (float)(s2[r] * 256 + s3[r]);
+                const float t = fmaf((float)s1[r], 65536.0f, lo);
+                f[v][r] = first ? t : f[v][r] + t;
+            }
+        }
+    };
+    const float inv = 1.0f / kFixScale;
+    const uint32_t bb = bw + lg;         // register r of this lane: beam bb + 4 r
+    const uint32_t out_blk = a.B * 128u; // bytes per 16-sample block of one channel
+    char *out8 = reinterpret_cast<char *>(a.beams);
+    // scale and store: lane l, register r = beam bw + (l >> 4) + 4 r, samples 2 m, 2 m + 1
+    auto finish = [&](auto whole, uint32_t blk, const floatx4 (&f)[4]) {
+        const uint32_t blkA = min(blk, last), blkB = min(blk + 1u, last);
+        char *base = out8 + ((uint64_t)c * a.nT16 + tt0 + blkA * tpr + slot) * out_blk; // wave-uniform
+        const uint32_t vo = (second ? (blkB - blkA) * tpr * out_blk : 0u) + bb * 128u + m * 16u;
+#pragma unroll
+        for (int r = 0; r < 4; r++) { // beam bb + 4 r
+            const floatx4 o = {f[0][r] * inv, f[1][r] * inv, f[2][r] * inv, f[3][r] * inv};
+            if (decltype(whole)::value || bb + 4u * r < a.B) {
+                floatx4 *dst = reinterpret_cast<floatx4 *>(base + (vo + 512u * r));
+#ifdef DCS_PROBES
+                if (a.probe == 4u) // same bytes, but each instruction writes ONE contiguous KiB (values land in the wrong places)
+                    dst = reinterpret_cast<floatx4 *>(base + ((r >= 2 ? (blkB - blkA) * tpr * out_blk : 0u) + bw * 128u + (r & 1) * 1024u + lane * 16u));
+#endif
+                if (a.plain_stores)
+                    *dst = o;
+                else
+                    __builtin_nontemporal_store(o, dst); // written once, read by another kernel: do not keep it in L2
+            }
+        }
+    };
+    auto run = [&](auto whole) {
+#ifdef DCS_PROBES
+        if (a.probe == 1u || a.probe == 3u || a.probe == 4u) { // stores only: what does the memory system make of this store pattern alone?
+            floatx4 f[4];
+#pragma unroll
+            for (int v = 0; v < 4; v++) f[v] = floatx4{(float)wre[0][0][0], (float)wre[0][1][1], (float)wim[0][0][2], (float)wim[0][2][3]};
+            for (uint32_t blk = 0; blk < n_blocks; blk += 2) finish(whole, blk, f);
+            return;
+        }
+        if (a.probe == 2u) { // loads and stores, no arithmetic between them
+            for (uint32_t blk = 0; blk < n_blocks; blk += 4) {
+                arrived(cur[0]);
+                arrived(cur[1]);
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    floatx4 f[4];
+#pragma unroll
+                    for (int v = 0; v < 4; v++)
+                        f[v] = floatx4{(float)cur[h][4 * v], (float)cur[h][4 * v + 1], (float)cur[h][4 * v + 2], (float)cur[h][4 * v + 3]};
+                    finish(whole, blk + 2u * h, f);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                fetch(cur[0], blk + 4u, 0);
+                fetch(cur[1], blk + 6u, 0);
+            }
+            return;
+        }
+#endif
+        if (STAGED) { // operands from LDS: nothing to wait for but the LDS itself
+            for (uint32_t blk = 0; blk < n_blocks; blk += 2) {
+                intx4 x[4];
+                floatx4 f[4];
+                fetch(cur[0], blk, 0);
+                transpose(cur[0], x);
+                contract(0, x, f, true);
+                finish(whole, blk, f);
+            }
+        } else if (NCH == 1) { // a trip = two pairs of sample blocks
+            for (uint32_t blk = 0; blk < n_blocks; blk += 4) {
+                arrived(cur[0]);
+                arrived(cur[1]);
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    intx4 x[4];
+                    floatx4 f[4];
+                    transpose(cur[h], x);
+                    contract(0, x, f, true);
+                    finish(whole, blk + 2u * h, f); // a pair past the end repeats the last block
+                }
+                __builtin_amdgcn_sched_barrier(0); // the loads stay behind the stores (see above)
+                fetch(cur[0], blk + 4u, 0);
+                fetch(cur[1], blk + 6u, 0);
+            }
+        } else { // a trip = two chunks of one pair
+            for (uint32_t blk = 0; blk < n_blocks; blk += 2) {
+                floatx4 f[4];
+#pragma unroll
+                for (int h = 0; h < NCH / 2; h++) {
+                    arrived(cur[0]);
+                    arrived(cur[1]);
+#pragma unroll
+                    for (int e = 0; e < 2; e++) {
+                        intx4 x[4];
+                        transpose(cur[e], x);
+                        contract(2 * h + e, x, f, h == 0 && e == 0);
+                    }
+                    if (h + 1 == NCH / 2) finish(whole, blk, f);
+                    const uint32_t nblk = h + 1 == NCH / 2 ? blk + 2u : blk;
+                    const uint32_t nch = h + 1 == NCH / 2 ? 0u : 2u * (h + 1);
+                    __builtin_amdgcn_sched_barrier(0); // the loads stay behind the stores (see above)
+                    fetch(cur[0], nblk, nch);
+                    fetch(cur[1], nblk, nch + 1u);
+                }
+            }
+        }
+    };
+    // the first trip's samples (STAGED: all of them) travel while the coefficients are made
+    if (!STAGED) fetch(cur[0], 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+#ifdef DCS_PROBES
+    if (a.probe == 3u || a.probe == 4u) { // no coefficients either: the store pattern alone
+#pragma unroll
+        for (int ch = 0; ch < NCH; ch++)
+#pragma unroll
+            for (int d = 0; d < 3; d++) wre[ch][d] = wim[ch][d] = intx4{(int)lane, d, ch, 1};
+    } else
+#endif
+    if (shared_w ? bw < a.B : !idle) make_coefficients(wre, wim);
+    if (STAGED) {
+        uint32_t *wx = reinterpret_cast<uint32_t *>(staged + a.share_off) + bt * (4u * 6u * 64u) + lane; // [tile][q][plane][lane]
+        if (shared_w && bw < a.B) {
+#pragma unroll
+            for (uint32_t q = 0; q < 4; q++)
+                if ((q & (tpr - 1u)) == slot) {
+#pragma unroll
+                    for (int d = 0; d < 3; d++) wx[(q * 6u + d) * 64u] = (uint32_t)wre[0][d][q], wx[(q * 6u + 3u + d) * 64u] = (uint32_t)wim[0][d][q];
+                }
+        }
+        __syncthreads(); // hipcc drains the LDS-DMA (vmcnt(0)) in front of it
+        if (idle) return;
+        if (shared_w) {
+#pragma unroll
+            for (uint32_t q = 0; q < 4; q++)
+                if ((q & (tpr - 1u)) != slot) {
+#pragma unroll
+                    for (int d = 0; d < 3; d++) wre[0][d][q] = (int)wx[(q * 6u + d) * 64u], wim[0][d][q] = (int)wx[(q * 6u + 3u + d) * 64u];
+                }
+        }
+    } else {
+        fetch(cur[1], NCH == 1 ? 2 : 0, NCH == 1 ? 0 : 1);
+    }
+    if (bw + 16u <= a.B)
+        run(std::true_type{});
+    else
+        run(std::false_type{});
+}
+
 } // namespace
 
 // LDS bytes of one workgroup for NBT beam tiles and A antennas.
@@ -193,32 +600,70 @@ hipError_t bf_launch_beamform_acc(const bf_bacc_args &a_in, hipStream_t stream)
 {
     bf_bacc_args a = a_in;
     if (a.A == 0 || a.B == 0 || a.C == 0 || a.nT16 == 0) return hipSuccess;
-    // beam tiles per workgroup: as many as the beams need while LDS still admits 6 workgroups per CU (26 KiB each);
-    // one tile whatever it takes beyond (256 antennas: 32 KiB)
+    if (a.A > 256u) return hipErrorInvalidValue; // not built
+    const bool chain = a.fp32_chain != 0u;
+    // beam tiles per workgroup: as many as the beams need; the fp32 form keeps its coefficient planes in LDS and
+    // takes as many as still admit 6 workgroups per CU (26 KiB each), one tile whatever it takes beyond
     int nbt = a.B > 32u ? 4 : (a.B > 16u ? 2 : 1);
-    while (nbt > 1 && bacc_lds_bytes(nbt, a.A) > 26u * 1024u) nbt >>= 1;
-    const size_t lds = bacc_lds_bytes(nbt, a.A);
-    if (lds > 64u * 1024u) return hipErrorInvalidValue; // more than 256 antennas: not built
+    while (chain && nbt > 1 && bacc_lds_bytes(nbt, a.A) > 26u * 1024u) nbt >>= 1;
+    const size_t lds = chain ? bacc_lds_bytes(nbt, a.A) : 0u;
+    a.nbt_log2 = nbt == 4 ? 2u : (nbt == 2 ? 1u : 0u);
     a.n_bgroups = (a.B + 16u * (uint32_t)nbt - 1u) / (16u * (uint32_t)nbt);
-    // 16-sample blocks per workgroup: all of them (W is generated once per workgroup), fewer while that leaves
-    // the chip under 4096 workgroups; whole rounds of 4 / nbt blocks
+    // 16-sample blocks per workgroup: whole rounds of 4 / nbt blocks, at most max_rounds (the coefficients are
+    // generated once per workgroup; but a launch of only a few thousand long-lived workgroups ends with most of the
+    // chip idle behind the last ones), fewer while that leaves the chip under 4096 workgroups
     const uint32_t tpr = 4u / (uint32_t)nbt;
-    // (at most 16 rounds: a CU holds ~5 workgroups, and a launch of only a few thousand long-lived workgroups ends
-    // with most of the chip idle behind the last ones -- 4096 workgroups of 64 rounds ran at 80 % of what 16384 of
-    // 16 rounds do)
+    const bool staged_form = !chain && a.A <= 64u && !a.unstaged; // at most 16 blocks (32 KiB of LDS) per workgroup
+    const uint32_t max_rounds = a.max_rounds ? a.max_rounds : (chain ? 16u : (staged_form ? 16u / tpr : 32u));
     uint32_t tiles = (a.nT16 + tpr - 1u) / tpr * tpr;
-    if (tiles > 16u * tpr) tiles = 16u * tpr;
-    while (tiles > tpr && (uint64_t)a.C * a.n_bgroups * ((a.nT16 + tiles - 1u) / tiles) < 4096u) tiles = ((tiles / tpr + 1u) / 2u) * tpr;
+    if (tiles > max_rounds * tpr) { // several workgroups per (channel, beam group): equal shares (17 blocks are 9 + 8, not 16 + 1)
+        const uint32_t parts = (a.nT16 + max_rounds * tpr - 1u) / (max_rounds * tpr);
+        tiles = ((a.nT16 + parts - 1u) / parts + tpr - 1u) / tpr * tpr;
+    }
+    // (the int8 form makes its coefficients once per wave -- half its arithmetic at 16 blocks -- so it only splits
+    // further while the chip, which holds 1280 of its workgroups, would not even be filled once)
+    const uint64_t enough = chain ? 4096u : 1280u;
+    while (tiles > tpr && (uint64_t)a.C * a.n_bgroups * ((a.nT16 + tiles - 1u) / tiles) < enough) tiles = ((tiles / tpr + 1u) / 2u) * tpr;
     a.tiles_per_wg = tiles;
     a.n_tgroups = (a.nT16 + tiles - 1u) / tiles;
     const uint64_t blocks = (uint64_t)a.C * a.n_bgroups * a.n_tgroups;
     if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
     const dim3 grid((uint32_t)blocks), block(kBlock);
-    if (nbt == 4)
-        hipLaunchKernelGGL(bf_beamform_acc_kernel<4>, grid, block, lds, stream, a);
-    else if (nbt == 2)
-        hipLaunchKernelGGL(bf_beamform_acc_kernel<2>, grid, block, lds, stream, a);
-    else
-        hipLaunchKernelGGL(bf_beamform_acc_kernel<1>, grid, block, lds, stream, a);
+    if (chain) {
+        if (nbt == 4)
+            hipLaunchKernelGGL(bf_beamform_acc_kernel<4>, grid, block, lds, stream, a);
+        else if (nbt == 2)
+            hipLaunchKernelGGL(bf_beamform_acc_kernel<2>, grid, block, lds, stream, a);
+        else
+            hipLaunchKernelGGL(bf_beamform_acc_kernel<1>, grid, block, lds, stream, a);
+    } else {
+        const uint32_t nch = a.A <= 64u ? 1u : (a.A <= 128u ? 2u : 4u);
+        const bool full = a.A == 64u * nch;
+#define DCS_I8(N)                                                                                   \
+    if (full)                                                                                       \
+        hipLaunchKernelGGL((bf_beamform_i8_kernel<N, true, false>), grid, block, 0, stream, a);   \
+    else                                                                                            \
+        hipLaunchKernelGGL((bf_beamform_i8_kernel<N, false, false>), grid, block, 0, stream, a)
+        if (nch == 1 && !a.unstaged) {
+            size_t stage_bytes = ((size_t)a.tiles_per_wg * a.A * 32u + 1023u) / 1024u * 1024u;
+            if (nbt < 4 && !a.no_share) { // waves that own the same tile share the making of its coefficients
+                a.share_off = (uint32_t)stage_bytes;
+                stage_bytes += (size_t)nbt * 4u * 6u * 64u * sizeof(uint32_t);
+            }
+            if (a.wg_per_cu >= 1u && a.wg_per_cu <= 5u && stage_bytes < 160u * 1024u / a.wg_per_cu) // residency cap: unused LDS
+                stage_bytes = (160u * 1024u / a.wg_per_cu) & ~1023u;
+            if (full)
+                hipLaunchKernelGGL((bf_beamform_i8_kernel<1, true, true>), grid, block, stage_bytes, stream, a);
+            else
+                hipLaunchKernelGGL((bf_beamform_i8_kernel<1, false, true>), grid, block, stage_bytes, stream, a);
+        } else if (nch == 1) {
+            DCS_I8(1);
+        } else if (nch == 2) {
+            DCS_I8(2);
+        } else {
+            DCS_I8(4);
+        }
+#undef DCS_I8
+    }
     return hipGetLastError();
 }

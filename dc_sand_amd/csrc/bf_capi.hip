@@ -8,6 +8,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -452,7 +453,7 @@ int dcs_bf_set_tuning(dcs_bf_context *c, const dcs_bf_tuning *t)
     if (t->rows_per_wave < 0 || t->rows_per_wave > 4) return DCS_ERR_INVALID_ARGUMENT;
     if (t->rows_same_tile < -1 || t->rows_same_tile > 1) return DCS_ERR_INVALID_ARGUMENT;
     if (t->xcd_remap < -1 || t->xcd_remap > 1) return DCS_ERR_INVALID_ARGUMENT;
-    if (t->math_mode < 0 || t->math_mode > 7) return DCS_ERR_INVALID_ARGUMENT;
+    if (t->math_mode < 0 || t->math_mode > 15) return DCS_ERR_INVALID_ARGUMENT;
     if ((t->math_mode & 4) && t->nontemporal == 0) return DCS_ERR_UNSUPPORTED; // the b16 arithmetic form exists with nontemporal stores only
 #ifdef DCS_PROBES
     if (t->probe_pace < 0 || t->probe_pace > 4096) return DCS_ERR_INVALID_ARGUMENT;
@@ -1029,6 +1030,15 @@ int beamform_acc_impl(dcs_bf_context *c, const dt_source &src, uint32_t nt, cons
     a.C = C;
     a.nT16 = nt / 16u;
     a.k = c->k;
+    a.fp32_chain = (c->tune.math_mode & 8) ? 1u : 0u; // math_mode bit 3: the fp32 fma-chain form
+#ifdef DCS_PROBES
+    if (const char *e = std::getenv("DCS_BACC_ROUNDS")) a.max_rounds = (uint32_t)std::atoi(e); // exploration only
+    if (const char *e = std::getenv("DCS_BACC_PROBE")) a.probe = (uint32_t)std::atoi(e);
+    if (const char *e = std::getenv("DCS_BACC_UNSTAGED")) a.unstaged = (uint32_t)std::atoi(e);
+    if (const char *e = std::getenv("DCS_BACC_PLAIN")) a.plain_stores = (uint32_t)std::atoi(e);
+    if (const char *e = std::getenv("DCS_BACC_NOSHARE")) a.no_share = (uint32_t)std::atoi(e);
+    if (const char *e = std::getenv("DCS_BACC_WPC")) a.wg_per_cu = (uint32_t)std::atoi(e);
+#endif
     return (int)bf_launch_beamform_acc(a, s);
 }
 } // namespace

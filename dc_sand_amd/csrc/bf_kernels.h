@@ -128,7 +128,17 @@ struct bf_bacc_args {
     const int8_t *ant;     // [C][nT16][A][16][2]
     float *beams;          // [C][nT16][B][16][2]
     uint32_t A, B, C, nT16;
-    uint32_t tiles_per_wg, n_bgroups, n_tgroups; // filled by the launcher
+    uint32_t fp32_chain;   // 0: exact fixed-point contraction on the int8 matrix pipe; 1: fp32 fma chain (v_mfma_f32_16x16x4_f32)
+    uint32_t max_rounds;   // 0 = the launcher's choice
+    uint32_t share_off;    // staged int8 form: LDS offset of the coefficient exchange (filled by the launcher; 0 = none)
+    uint32_t no_share;     // staged int8 form: every wave makes all its coefficients
+    uint32_t plain_stores; // int8 form: ordinary instead of nontemporal stores
+    uint32_t wg_per_cu;    // staged int8 form: at most this many workgroups resident per CU (0 = as many as fit)
+    uint32_t unstaged;     // int8 form, <= 64 antennas: operands straight from global memory instead of through LDS
+#ifdef DCS_PROBES
+    uint32_t probe;        // probes build only: 1 = stores only, 2 = loads and stores without arithmetic
+#endif
+    uint32_t tiles_per_wg, n_bgroups, n_tgroups, nbt_log2; // filled by the launcher
     dcs_bf_consts k;
 };
 hipError_t bf_launch_beamform_acc(const bf_bacc_args &a, hipStream_t stream);

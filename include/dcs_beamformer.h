@@ -225,15 +225,21 @@ int dcs_bf_generate_and_beamform_dt(dcs_bf_context *ctx, const float *dt, uint32
  * coefficients every ACCUMULATIONS_BEFORE_NEW_COEFFS time units (BeamformerParameters.h:17; the utilisation
  * model BCT.cu:426-448).  Here the coefficients of ONE time -- time index t_coeff (fDeltaTime as
  * dcs_bf_delta_times gives it), or fDeltaTime by value -- are generated once per (channel, antenna, beam), into
- * LDS, never HBM, and applied to nt samples (a multiple of 16; tensors and table ordering exactly as
+ * registers, never HBM, and applied to nt samples (a multiple of 16; tensors and table ordering exactly as
  * dcs_bf_generate_and_beamform):
  *   beams[c][t/16][b][t%16] = ( sum_a cos(rot[a][b][c]) * re[c][t][a] , sum_a sin(rot[a][b][c]) * im[c][t][a] )
- * Per channel two real contractions over the antennas on the fp32 matrix cores (v_mfma_f32_16x16x4_f32):
- * exact fp32 products accumulated as an fma chain in antenna order, so the result differs from the verifier's
- * loop with the coefficient held (BCT.cu:363-414: sum += coeff * sample, multiply and add rounded separately)
- * by the chain's roundings only -- |difference| <= 2e-5 * nr_stations against the reference's tolerance of 1e-1
- * (runBeamformerTests.cpp:15).  nr_stations <= 256; d_antenna 16-byte aligned.  Not capturable (stages one
- * fDeltaTime through pinned memory; allocates its terms table on first use). */
+ * Per channel two real contractions over the antennas, on the matrix cores.  Default form: EXACT integer
+ * arithmetic on the int8 pipe (v_mfma_i32_16x16x64_i8).  The samples are int8; each coefficient w (|w| <= 1) is
+ * taken as the 24-bit fixed-point number rint(w * 8355711) = three signed 8-bit digits, so a plane is three
+ * integer contractions whose sums are exact and independent of the antenna order, recombined and divided by
+ * 8355711 in fp32 at the end.  Against the exact sum of the fp32 coefficients times the samples the result is
+ * within 9e-8 * sum_a |sample_a| + 1.5 ulp -- closer than the verifier's own fp32 loop (BCT.cu:363-414 with the
+ * coefficient held: sum += coeff * sample, whose partial sums round at every antenna) -- and within
+ * 2e-5 * nr_stations of that loop, against the reference's tolerance of 1e-1 (runBeamformerTests.cpp:15).
+ * dcs_bf_tuning.math_mode bit 3 selects the other form: v_mfma_f32_16x16x4_f32, exact fp32 products
+ * accumulated as an fma chain in antenna order (differs from the verifier's loop by the chain's single
+ * roundings only; same bound; 1/32 of the int8 pipe's rate).  nr_stations <= 256; d_antenna 16-byte aligned.
+ * Not capturable (stages one fDeltaTime through pinned memory; allocates its terms table on first use). */
 int dcs_bf_beamform_accumulated(dcs_bf_context *ctx, uint64_t t_coeff, uint32_t nt, const int8_t *d_antenna,
                                 size_t antenna_bytes, float *d_beams, size_t beams_bytes, void *stream);
 int dcs_bf_beamform_accumulated_dt(dcs_bf_context *ctx, float dt_coeff, uint32_t nt, const int8_t *d_antenna,
@@ -281,7 +287,8 @@ struct dcs_bf_tuning {
                               * equal to it for 99.8 % of them (0.9 % differ in [1, 32768); tests/test_numerics.py, by
                               * exhaustion).  The reference rounds whatever __sincosf returned and never checks it
                               * (BeamformerKernels.cu:113-115,182-184; BCT.cu:282-287).  Default off; fp32 output and
-                              * the rows form are unaffected. */
+                              * the rows form are unaffected.  Bit 3 (value 8): dcs_bf_beamform_accumulated runs its
+                              * fp32 fma-chain form instead of the exact fixed-point one. */
     int32_t wg_per_cu;       /* form 1: 0 = default (fp32: 6 for launches that oversubscribe the chip), -1 = no limit, 2..7 = at most this many workgroups resident per CU (the launch
                               * asks for unused dynamic LDS to that end): fewer waves in flight keep the store stream
                               * closer to address order (profiles/r01_store_patterns.md, "Fewer workgroups in flight") */

@@ -57,6 +57,11 @@ int dcs_probe_reduce(const void *d_in, size_t bytes, uint64_t *checksum, float *
  * FLOP per launch = blocks * 4 * iters * 16 * (2048 or 4096). */
 int dcs_probe_mfma(int which, uint32_t blocks, uint32_t iters, float *d_out, void *stream);
 
+/* Device-to-device copy by the leanest kernel (one 16-byte load and store per thread, `per_thread` of them `stride_kib`
+ * KiB apart when > 1; workgroups in address order): the mixed read + write rate the HBM system sustains, which the
+ * coefficient-reuse beamformer at 16 beams (as many bytes in as out) is read against.  store_mode 0 plain, 1 nontemporal. */
+int dcs_probe_copy(const void *d_in, void *d_out, size_t bytes, int store_mode, int per_thread, void *stream);
+
 #pragma GCC visibility pop
 #ifdef __cplusplus
 }

@@ -344,6 +344,21 @@ __global__ void __launch_bounds__(kBlock) bf_probe_mfma_kernel(float *out, uint3
 
 } // namespace
 
+namespace {
+template <bool NT, int PER>
+__global__ void __launch_bounds__(256) probe_copy_kernel(const floatx4 *in, floatx4 *out, size_t n_vec)
+{
+    // a workgroup owns PER consecutive 4-KiB pieces; thread t copies vector t of each
+    const size_t base = (size_t)blockIdx.x * (256u * PER) + threadIdx.x;
+    floatx4 v[PER];
+#pragma unroll
+    for (int i = 0; i < PER; i++) v[i] = base + 256u * i < n_vec ? in[base + 256u * i] : floatx4{0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < PER; i++)
+        if (base + 256u * i < n_vec) store_global<NT>(out + base + 256u * i, v[i]);
+}
+} // namespace
+
 extern "C" {
 
 // MFMA issue-rate probe: grid x 4 waves, each `iters` x 16 MFMAs (which: see bf_probe_mfma_kernel).
@@ -366,6 +381,32 @@ int dcs_probe_sincos(int which, const float *d_x, size_t n, float *d_sin, float 
 {
     if (which < 0 || which > 4 || (n && (!d_x || !d_sin || !d_cos))) return DCS_ERR_INVALID_ARGUMENT;
     return (int)bf_launch_probe_sincos(which, d_x, n, d_sin, d_cos, as_stream(stream));
+}
+
+int dcs_probe_copy(const void *d_in, void *d_out, size_t bytes, int store_mode, int per_thread, void *stream)
+{
+    if (!d_in || !d_out || (bytes % 16u) || (reinterpret_cast<uintptr_t>(d_in) & 15u) || (reinterpret_cast<uintptr_t>(d_out) & 15u))
+        return DCS_ERR_INVALID_ARGUMENT;
+    const size_t n_vec = bytes / 16u;
+    const floatx4 *in = static_cast<const floatx4 *>(d_in);
+    floatx4 *out = static_cast<floatx4 *>(d_out);
+    hipStream_t s = as_stream(stream);
+#define DCS_COPY(PER)                                                                                                  \
+    {                                                                                                                  \
+        const size_t blocks = (n_vec + 256u * PER - 1u) / (256u * PER);                                                \
+        if (blocks > 0x7fffffffull) return DCS_ERR_INVALID_ARGUMENT;                                                   \
+        if (store_mode)                                                                                                \
+            hipLaunchKernelGGL((probe_copy_kernel<true, PER>), dim3((uint32_t)blocks), dim3(256), 0, s, in, out, n_vec); \
+        else                                                                                                           \
+            hipLaunchKernelGGL((probe_copy_kernel<false, PER>), dim3((uint32_t)blocks), dim3(256), 0, s, in, out, n_vec); \
+    }
+    if (per_thread == 1) DCS_COPY(1)
+    else if (per_thread == 2) DCS_COPY(2)
+    else if (per_thread == 4) DCS_COPY(4)
+    else if (per_thread == 8) DCS_COPY(8)
+    else return DCS_ERR_INVALID_ARGUMENT;
+#undef DCS_COPY
+    return (int)hipGetLastError();
 }
 
 int dcs_probe_fill(void *d_out, size_t bytes, int nontemporal, void *stream)

@@ -18,6 +18,7 @@ _VP = c_void_p
 SIGNATURES = [
     ("dcs_probe_sincos", c_int, [c_int, _VP, c_size_t, _VP, _VP, _VP]),
     ("dcs_probe_fill", c_int, [_VP, c_size_t, c_int, _VP]),
+    ("dcs_probe_copy", c_int, [_VP, _VP, c_size_t, c_int, c_int, _VP]),
     ("dcs_probe_one_store", c_int, [_VP, c_size_t, c_int, c_int, c_uint32, _VP]),
     ("dcs_probe_reduce", c_int, [_VP, c_size_t, POINTER(c_uint64), POINTER(c_float), _VP]),
     ("dcs_probe_mfma", c_int, [c_int, c_uint32, c_uint32, _VP, _VP]),
@@ -67,6 +68,11 @@ def sincos(which: int, d_x, n: int, d_sin, d_cos, stream=None) -> None:
 
 def fill(d_out, nbytes: int, nontemporal: int = 1, stream=None) -> None:
     _check(lib().dcs_probe_fill(c_void_p(int(d_out)), int(nbytes), int(nontemporal), _s(stream)), "dcs_probe_fill")
+
+
+def copy(d_in, d_out, nbytes: int, store_mode: int = 1, per_thread: int = 1, stream=None) -> None:
+    _check(lib().dcs_probe_copy(c_void_p(int(d_in)), c_void_p(int(d_out)), int(nbytes), int(store_mode), int(per_thread), _s(stream)),
+           "dcs_probe_copy")
 
 
 def store_pattern(d_out, rows, cols_kib, qb, rb, order=0, xcd_remap=0, store_mode=1, block_threads=256, stream=None) -> None:

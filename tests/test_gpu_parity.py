@@ -1193,17 +1193,21 @@ def test_autotune_measures_a_large_shape_once(gpu, oracle):
 
 
 # ---- beamformer with coefficient reuse on the matrix cores ("general version")
+@pytest.mark.parametrize("math_mode", [0, 8])
 @pytest.mark.parametrize("A,B,C,nt", [(64, 16, 64, 256), (64, 16, 5, 32), (64, 64, 7, 64), (64, 40, 3, 48), (8, 4, 5, 16), (37, 21, 9, 48),
                                        (130, 3, 4, 16), (4, 40, 7, 32), (9, 5, 3, 16), (129, 33, 2, 32), (256, 17, 2, 16), (1, 1, 1, 16),
-                                       (66, 70, 2, 80)])
-def test_beamform_accumulated_on_the_matrix_cores(gpu, oracle, A, B, C, nt):
+                                       (66, 70, 2, 80), (128, 16, 3, 64), (192, 48, 2, 32), (200, 20, 2, 32), (64, 1024, 1, 32)])
+def test_beamform_accumulated_on_the_matrix_cores(gpu, oracle, A, B, C, nt, math_mode):
     """dcs_bf_beamform_accumulated: the coefficients of ONE time applied to nt samples as two real contractions over the
-    antennas on v_mfma_f32_16x16x4_f32, against the verifier's beamformer with the coefficient held
-    (BeamformerCoefficientTest.cu:363-414).  The matrix instruction is an fp32 fma chain in antenna order, the verifier
-    multiplies and adds with separate roundings, and each coefficient is within 1 ULP: |difference| <= 2e-5 * A (the
-    bound the per-sample fused kernel is held to); the reference's own tolerance is 1e-1 (runBeamformerTests.cpp:15).
-    Shapes cover every beam-tile count (1, 2, 4 per workgroup), ragged antennas / beams / sample blocks, several
-    64-antenna chunks and the 256-antenna limit."""
+    antennas on the matrix cores, against the verifier's beamformer with the coefficient held
+    (BeamformerCoefficientTest.cu:363-414).  Both forms: the default exact fixed-point contraction on the int8 pipe
+    (24-bit coefficients as three signed digits; sums exact) and (math_mode 8) the fp32 fma chain on
+    v_mfma_f32_16x16x4_f32.  The verifier multiplies and adds with separate roundings, and each coefficient is within
+    1 ULP: |difference| <= 2e-5 * A (the bound the per-sample fused kernel is held to); the reference's own tolerance is
+    1e-1 (runBeamformerTests.cpp:15).  The fixed-point form is also held to its own, much tighter, bound against the
+    sum in exact (fp64) arithmetic of the oracle's fp32 coefficients: 2.5e-7 * sum_a |sample_a| + 2e-7 * |sum|.
+    Shapes cover every beam-tile count (1, 2, 4 per workgroup), ragged antennas / beams / sample blocks, 1-4
+    64-antenna chunks (whole and partial) and the 256-antenna limit."""
     from dc_sand_amd import BeamformerParameters
     from dc_sand_amd.generator import SteeringCoefficientGenerator, delta_times, simulate_input
 
@@ -1218,6 +1222,8 @@ def test_beamform_accumulated_on_the_matrix_cores(gpu, oracle, A, B, C, nt):
     exp = oracle.beamform_accumulated(op, table, delta_times(bp, t_coeff, 1)[0], nt, ant)
     g = SteeringCoefficientGenerator(bp)
     g.upload_delays(table)
+    if math_mode:
+        g.set_tuning(math_mode=math_mode)
     d_ant = gpu.mem_alloc(ant.nbytes)
     gpu.memcpy_htod(d_ant, ant)
     d_beams = gpu.mem_alloc(exp.nbytes + 64)
@@ -1231,6 +1237,13 @@ def test_beamform_accumulated_on_the_matrix_cores(gpu, oracle, A, B, C, nt):
     diff = np.abs(got - exp)
     assert diff.max() <= 2e-5 * A + 1e-6, diff.max()
     assert oracle.compare(got, exp, 1e-1) == -1
+    if math_mode == 0:
+        # exact-arithmetic sum of the oracle's coefficients (table [b*A + a] -> the generator's [a*B + b])
+        coef = oracle.generate_dt(op, np.ascontiguousarray(table.reshape(B, A).T).ravel(), delta_times(bp, t_coeff, 1)[0])[0].astype(np.float64)
+        x = ant.reshape(C, nt // 16, A, 16, 2).astype(np.float64)
+        exact = np.einsum("cabk,ctaik->ctbik", coef, x)  # [c][t/16][b][t%16][re, im]
+        mag = np.abs(x).sum(axis=2)[:, :, None, :, :]   # sum_a |sample|, per (c, t/16, t%16, plane)
+        assert np.all(np.abs(got - exact) <= 2.5e-7 * mag + 2e-7 * np.abs(exact) + 1e-30)
     # fDeltaTime by value gives the same bits
     g.beamform_accumulated(d_ant, ant.nbytes, d_beams, exp.nbytes, nt, dt_coeff=float(delta_times(bp, t_coeff, 1)[0]))
     got2 = np.empty(exp.shape, dtype=np.float32)

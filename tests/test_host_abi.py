@@ -50,7 +50,7 @@ def test_product_library_exports_no_measurement_apparatus(dcs_lib):
     pexp = {l.split()[-1] for l in psyms.splitlines() if " T " in l}
     text = re.sub(r"/\*.*?\*/", "", (ROOT / "include" / "dcs_probes.h").read_text(), flags=re.S)
     declared_probes = set(re.findall(r"\b(dcs_probe_[a-z0-9_]+)\s*\(", text))
-    assert len(declared_probes) == 6 and declared_probes <= pexp
+    assert len(declared_probes) == 7 and declared_probes <= pexp
     assert set(_declared_functions()) <= pexp  # the probes library is a superset build
 
 

@@ -27,6 +27,7 @@ the tests use.  The store-only studies need the probes build (include/dcs_probes
 from __future__ import annotations
 
 import argparse
+import ctypes
 import json
 import sys
 import time
@@ -224,14 +225,34 @@ def cmd_bfacc(args):
         ab, bb = A * C * nt * 2, B * C * nt * 8
         d_ant, d_beams = device.mem_alloc(ab), device.mem_alloc(bb)
         device.memset(d_ant, 3, ab)
-        ms = min(per_launch_ms(lambda: g.beamform_accumulated(d_ant, ab, d_beams, bb, nt, t_coeff=1)) for _ in range(2))
-        flop = 4.0 * A * B * C * nt
-        print(f"{A}ant x {B}beam x {C}chan x {nt}samples: {ms * 1e3:.1f} us -> {A * B * C * nt / ms / 1e9:.2f} T coefficient-products/s, "
-              f"{(ab + bb) / ms / 1e9:.2f} TB/s algorithmic ({(ab + bb) / ms / 1e9 / 8 * 100:.1f} % of 8 TB/s), {flop / ms / 1e9:.1f} TFLOP/s fp32 MFMA "
-              f"({flop / ms / 1e9 / 155 * 100:.1f} % of 155)", flush=True)
+        for mode in (int(m) for m in args.modes.split(",")):
+            g.set_tuning(math_mode=mode)
+            ms = min(per_launch_ms(lambda: g.beamform_accumulated(d_ant, ab, d_beams, bb, nt, t_coeff=1)) for _ in range(2))
+            flop = 4.0 * A * B * C * nt
+            form = "fp32 chain" if mode & 8 else "int8 fixed point"
+            print(f"{A}ant x {B}beam x {C}chan x {nt}samples [{form}]: {ms * 1e3:.1f} us -> {A * B * C * nt / ms / 1e9:.2f} T coefficient-products/s, "
+                  f"{(ab + bb) / ms / 1e9:.2f} TB/s algorithmic ({(ab + bb) / ms / 1e9 / 8 * 100:.1f} % of 8 TB/s), {flop / ms / 1e9:.1f} TFLOP/s-equivalent "
+                  f"({flop / ms / 1e9 / 155 * 100:.1f} % of the fp32 MFMA peak)", flush=True)
         g.close()
         d_ant.free()
         d_beams.free()
+
+
+def cmd_copy(args):
+    """Mixed read + write ceiling: device-to-device copies (lean kernel in address order; hipMemcpyDtoD)."""
+    from probes import dcs_probes as pr
+    from dc_sand_amd import _lib
+
+    nbytes = 4 * 2 ** 30
+    a, b = device.mem_alloc(nbytes), device.mem_alloc(nbytes)
+    device.memset(a, 1, nbytes)
+    for per in (1, 2, 4, 8):
+        for mode in (0, 1):
+            ms = min(per_launch_ms(lambda: pr.copy(a, b, nbytes, mode, per), timed_ms=30) for _ in range(2))
+            print(f"copy kernel, {per} x 16 B per thread, {'nontemporal' if mode else 'plain'} stores: {2 * nbytes / ms / 1e9:.2f} TB/s (read + write)", flush=True)
+    ms = min(per_launch_ms(lambda: _lib.check(_lib.lib().dcs_memcpy_dtod(ctypes.c_void_p(int(b)), ctypes.c_void_p(int(a)), nbytes, None), "dtod"),
+                           timed_ms=30) for _ in range(2))
+    print(f"hipMemcpyDtoDAsync: {2 * nbytes / ms / 1e9:.2f} TB/s (read + write)", flush=True)
 
 
 def cmd_mfma(args):
@@ -415,8 +436,10 @@ def main():
     p.add_argument("--bits", type=int, default=16, choices=[16, 32])
     sub.add_parser("fused")
     sub.add_parser("mfma")
+    sub.add_parser("copy")
     p = sub.add_parser("bfacc")
     p.add_argument("--shape", default="", help="AxBxCxNT: one shape only (PMC passes)")
+    p.add_argument("--modes", default="0,8", help="math_mode values: 0 = int8 fixed point, 8 = fp32 chain")
     p = sub.add_parser("stream")
     p.add_argument("--model-step-us", type=float, default=200.0)
     sub.add_parser("pmc")
@@ -439,7 +462,7 @@ def main():
     device.require_device()
     device.set_device(0)
     print("device:", device.device_name(0), flush=True)
-    {"geometry": cmd_geometry, "refshape": cmd_refshape, "fp16": cmd_fp16, "fused": cmd_fused, "mfma": cmd_mfma, "bfacc": cmd_bfacc, "stream": cmd_stream, "pmc": cmd_pmc,
+    {"geometry": cmd_geometry, "refshape": cmd_refshape, "fp16": cmd_fp16, "fused": cmd_fused, "mfma": cmd_mfma, "copy": cmd_copy, "bfacc": cmd_bfacc, "stream": cmd_stream, "pmc": cmd_pmc,
      "sustained": cmd_sustained, "stores": cmd_stores, "sincos": cmd_sincos}[args.cmd](args)
 
 
