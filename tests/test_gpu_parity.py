@@ -1196,7 +1196,8 @@ def test_autotune_measures_a_large_shape_once(gpu, oracle):
 @pytest.mark.parametrize("math_mode", [0, 8])
 @pytest.mark.parametrize("A,B,C,nt", [(64, 16, 64, 256), (64, 16, 5, 32), (64, 64, 7, 64), (64, 40, 3, 48), (8, 4, 5, 16), (37, 21, 9, 48),
                                        (130, 3, 4, 16), (4, 40, 7, 32), (9, 5, 3, 16), (129, 33, 2, 32), (256, 17, 2, 16), (1, 1, 1, 16),
-                                       (66, 70, 2, 80), (128, 16, 3, 64), (192, 48, 2, 32), (200, 20, 2, 32), (64, 1024, 1, 32)])
+                                       (66, 70, 2, 80), (128, 16, 3, 64), (192, 48, 2, 32), (200, 20, 2, 32), (64, 1024, 1, 32),
+                                       (64, 32, 3, 112), (64, 24, 2, 272), (64, 16, 2, 592), (48, 16, 3, 48), (64, 64, 2, 272)])
 def test_beamform_accumulated_on_the_matrix_cores(gpu, oracle, A, B, C, nt, math_mode):
     """dcs_bf_beamform_accumulated: the coefficients of ONE time applied to nt samples as two real contractions over the
     antennas on the matrix cores, against the verifier's beamformer with the coefficient held
@@ -1206,7 +1207,8 @@ def test_beamform_accumulated_on_the_matrix_cores(gpu, oracle, A, B, C, nt, math
     1 ULP: |difference| <= 2e-5 * A (the bound the per-sample fused kernel is held to); the reference's own tolerance is
     1e-1 (runBeamformerTests.cpp:15).  The fixed-point form is also held to its own, much tighter, bound against the
     sum in exact (fp64) arithmetic of the oracle's fp32 coefficients: 2.5e-7 * sum_a |sample_a| + 2e-7 * |sum|.
-    Shapes cover every beam-tile count (1, 2, 4 per workgroup), ragged antennas / beams / sample blocks, 1-4
+    Shapes cover every beam-tile count (1, 2, 4 per workgroup: coefficients shared by 4, 2, 1 waves), ragged antennas /
+    beams / sample blocks, odd block counts and more than 16 blocks per (channel, beam group) (several workgroups), 1-4
     64-antenna chunks (whole and partial) and the 256-antenna limit."""
     from dc_sand_amd import BeamformerParameters
     from dc_sand_amd.generator import SteeringCoefficientGenerator, delta_times, simulate_input
@@ -1271,10 +1273,14 @@ def test_beamform_accumulated_slow_class_and_limits(gpu, oracle):
     d_ant = gpu.mem_alloc(ant.nbytes)
     gpu.memcpy_htod(d_ant, ant)
     d_beams = gpu.mem_alloc(exp.nbytes)
-    g.beamform_accumulated(d_ant, ant.nbytes, d_beams, exp.nbytes, 32, dt_coeff=float(dt))
-    got = np.empty_like(exp)
-    gpu.memcpy_dtoh(got, d_beams)
-    assert np.abs(got - exp).max() <= 2e-4 * 9
+    for math_mode in (0, 8):  # the fixed-point form and the fp32 chain
+        g.set_tuning(math_mode=math_mode)
+        gpu.memset(d_beams, 0xFF, exp.nbytes)
+        g.beamform_accumulated(d_ant, ant.nbytes, d_beams, exp.nbytes, 32, dt_coeff=float(dt))
+        got = np.empty_like(exp)
+        gpu.memcpy_dtoh(got, d_beams)
+        assert np.abs(got - exp).max() <= 2e-4 * 9
+    g.set_tuning()
     with pytest.raises(_lib.DcsError) as e:
         g.beamform_accumulated(d_ant, ant.nbytes, d_beams, exp.nbytes, 24, t_coeff=0)
     assert e.value.status == _lib.DCS_ERR_INVALID_ARGUMENT
