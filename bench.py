@@ -117,7 +117,8 @@ def extras(gen, bp, out, out_bytes, sh, device, sustain_seconds: float) -> dict:
       200 us per tick (dcs_bf_stream_tick_dt): the full tensor's update period (it cannot meet 200 us: 16 GiB
       need >= 2.15 ms at the 8 TB/s peak) and the largest channel slab whose period stays <= 200 us;
     * ``fp16_output``: the b16 output mode (SURVEY 8 f2), exact-RNE form and the opt-in b16 arithmetic form;
-    * ``fused_generate_and_beamform`` (f1) on a 64 x 64 x 4096 x 64 problem."""
+    * ``fused_generate_and_beamform`` (f1) on a 64 x 64 x 4096 x 64 problem;
+    * ``beamform_accumulated``: the coefficient-reuse beamformer (256 samples per coefficient) at 16 and 256 beams."""
     from dc_sand_amd import BeamformerParameters
     from dc_sand_amd.generator import SteeringCoefficientGenerator, simulate_input
 
@@ -215,6 +216,28 @@ def extras(gen, bp, out, out_bytes, sh, device, sustain_seconds: float) -> dict:
                                           "shape": f"{A}ant x {B}beam x {C}chan x {nt}samples", "bound": "fp32 VALU (no coefficient reaches HBM)"}
     device.stream_synchronize(sh)
     g.close()
+    d_ant.free()
+    d_beams.free()
+    # -- the same beamformer with the coefficients of ONE time reused for 256 samples (ACCUMULATIONS_BEFORE_NEW_COEFFS,
+    #    BeamformerParameters.h:17): exact fixed-point contraction on the int8 matrix pipe; roofline = HBM
+    res["beamform_accumulated"] = []
+    for (A, B, C, nt) in ((64, 16, 4096, 256), (64, 256, 1024, 256)):
+        fp = BeamformerParameters(NR_CHANNELS=C, NR_STATIONS=A, NR_BEAMS=B, NR_SAMPLES_PER_CHANNEL=nt)
+        g = SteeringCoefficientGenerator(fp)
+        g.upload_delays(simulate_input(fp), stream=sh)
+        ant_bytes, beam_bytes = A * C * nt * 2, B * C * nt * 8
+        d_ant, d_beams = device.mem_alloc(ant_bytes), device.mem_alloc(beam_bytes)
+        device.memset(d_ant, 3, ant_bytes, stream=sh)
+        ms = timed(lambda: g.beamform_accumulated(d_ant, ant_bytes, d_beams, beam_bytes, nt, t_coeff=1, stream=sh), n=40, warm=20)
+        res["beamform_accumulated"].append({
+            "value": A * B * C * nt / ms / 1e9, "unit": "T coefficient-products/s", "ms": ms, "shape": f"{A}ant x {B}beam x {C}chan x {nt}samples",
+            "algorithmic_bytes": ant_bytes + beam_bytes, "hbm_GBps": (ant_bytes + beam_bytes) / ms / 1e6,
+            "frac_of_hbm_peak": (ant_bytes + beam_bytes) / ms / 1e6 / HBM_PEAK_GBPS,
+            "bound": "HBM (2 B per antenna and sample in, 8 B per beam and sample out); v_mfma_i32_16x16x64_i8 on 24-bit fixed-point coefficients"})
+        device.stream_synchronize(sh)
+        g.close()
+        d_ant.free()
+        d_beams.free()
     return res
 
 

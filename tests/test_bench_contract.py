@@ -72,6 +72,8 @@ def test_single_gpu_line_with_cpu_baseline():
     assert st["largest_slab_at_200us"] is None or st["largest_slab_at_200us"]["period_us"] <= 200.0
     assert am["fp16_output"]["math_mode"] == 0 and am["fp16_output_b16_arithmetic"]["math_mode"] == 4
     assert am["fused_generate_and_beamform"]["value"] > 0
+    ba = am["beamform_accumulated"]
+    assert len(ba) == 2 and all(x["value"] > 0 and 0 < x["frac_of_hbm_peak"] < 1 and x["unit"] == "T coefficient-products/s" for x in ba)
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] == 1 and c["unit"] == "Gcoeff/s" and c["value"] > 0 and c["sample"]
     assert c["gpu_vs_oracle_spot_check"]["over_1ulp"] == 0

@@ -368,7 +368,8 @@ def cmd_stores(args):
     nbytes = 16 * 2 ** 30
     buf = device.mem_alloc(nbytes)
     if args.kind == "pattern":  # rows x cols KiB matrix, workgroup rectangles of rb rows x qb KiB
-        rows, cols = 32768, 512
+        cols = args.cols_kib
+        rows = nbytes // (cols * 1024)
         for qb in [int(v) for v in args.qb.split(",")]:
             for rb in [int(v) for v in args.rb.split(",")]:
                 for mode in [int(v) for v in args.mode.split(",")]:
@@ -454,6 +455,7 @@ def main():
     p.add_argument("--xcd", type=int, default=0)
     p.add_argument("--mode", default="1")
     p.add_argument("--threads", type=int, default=256)
+    p.add_argument("--cols-kib", type=int, default=512, help="row length of the pattern matrix in KiB (32: the beamformer's output at 256 beams)")
     p.add_argument("--spt", default="1,2,3,4,8")
     p.add_argument("--pace", default="0")
     p.add_argument("--cpb", default="8,12,16")
