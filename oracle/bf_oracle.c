@@ -328,8 +328,8 @@ struct cmp_job {
     const struct dcs_oracle_delay_vals *delays;
     const float *dt;
     size_t nt, c0, nc, cb, ce; /* this thread: channels [cb, ce) of the slab [c0, c0+nc) */
-    const float *got;
-    int reading;
+    const void *got; /* float [..][2], or (half = 1) binary16 bit patterns in the same order */
+    int reading, half;
     uint64_t hist[4];
     uint32_t max_ulp;
     int64_t first_over;
@@ -347,7 +347,15 @@ static void *cmp_worker(void *arg)
                 float e[2];
                 coeff_reading(j->p, j->delays[i], fDeltaTime, c, j->reading, &e[0], &e[1]);
                 for (int k = 0; k < 2; k++) {
-                    const uint32_t d = dcs_oracle_ulp_diff(j->got[base + 2 * i + k], e[k]);
+                    uint32_t d;
+                    if (j->half) { /* expectation: RN-even binary16 of the verifier's fp32; distance in binary16 ulps */
+                        const uint16_t g = ((const uint16_t *)j->got)[base + 2 * i + k], w = dcs_oracle_f32_to_f16_rn(e[k]);
+                        const int32_t gi = (g & 0x8000u) ? -(int32_t)(g & 0x7fffu) : (int32_t)(g & 0x7fffu);
+                        const int32_t wi = (w & 0x8000u) ? -(int32_t)(w & 0x7fffu) : (int32_t)(w & 0x7fffu);
+                        d = (uint32_t)(gi > wi ? gi - wi : wi - gi);
+                    } else {
+                        d = dcs_oracle_ulp_diff(((const float *)j->got)[base + 2 * i + k], e[k]);
+                    }
                     j->hist[d > 3 ? 3 : d]++;
                     if (d > j->max_ulp) j->max_ulp = d;
                     if (d > 1 && j->first_over < 0) j->first_over = (int64_t)(base + 2 * i + k);
@@ -358,10 +366,10 @@ static void *cmp_worker(void *arg)
     return NULL;
 }
 
-double dcs_oracle_compare_generated(const struct dcs_oracle_params *p,
+static double compare_generated(const struct dcs_oracle_params *p,
                                     const struct dcs_oracle_delay_vals *delays,
                                     const float *dt, size_t nt, size_t c0, size_t nc,
-                                    const float *got, int nthreads, int reading,
+                                    const void *got, int half, int nthreads, int reading,
                                     uint64_t hist[4], uint32_t *max_ulp, int64_t *first_over_1ulp)
 {
     if (nthreads < 1) nthreads = 1;
@@ -372,7 +380,7 @@ double dcs_oracle_compare_generated(const struct dcs_oracle_params *p,
     size_t per = nc / (size_t)nthreads, rem = nc % (size_t)nthreads, c = c0;
     for (int i = 0; i < nthreads; i++) {
         size_t cnt = per + ((size_t)i < rem ? 1 : 0);
-        jobs[i] = (struct cmp_job){p, delays, dt, nt, c0, nc, c, c + cnt, got, reading == 1 ? 1 : 0, {0, 0, 0, 0}, 0, -1};
+        jobs[i] = (struct cmp_job){p, delays, dt, nt, c0, nc, c, c + cnt, got, reading == 1 ? 1 : 0, half, {0, 0, 0, 0}, 0, -1};
         c += cnt;
         if (i > 0) pthread_create(&th[i], NULL, cmp_worker, &jobs[i]);
     }
@@ -393,6 +401,27 @@ double dcs_oracle_compare_generated(const struct dcs_oracle_params *p,
     if (max_ulp) *max_ulp = mx;
     if (first_over_1ulp) *first_over_1ulp = first;
     return secs;
+}
+
+double dcs_oracle_compare_generated(const struct dcs_oracle_params *p,
+                                    const struct dcs_oracle_delay_vals *delays,
+                                    const float *dt, size_t nt, size_t c0, size_t nc,
+                                    const float *got, int nthreads, int reading,
+                                    uint64_t hist[4], uint32_t *max_ulp, int64_t *first_over_1ulp)
+{
+    return compare_generated(p, delays, dt, nt, c0, nc, got, 0, nthreads, reading, hist, max_ulp, first_over_1ulp);
+}
+
+/* The same for the packed binary16 output (BeamformerKernels.cu:113-115, 182-184: __floats2half2_rn of the pair; the
+ * reference never verifies it, BeamformerCoefficientTest.cu:282-287): expectation RN-even(verifier's fp32), distances
+ * in binary16 ulps. */
+double dcs_oracle_compare_generated_f16(const struct dcs_oracle_params *p,
+                                        const struct dcs_oracle_delay_vals *delays,
+                                        const float *dt, size_t nt, size_t c0, size_t nc,
+                                        const uint16_t *got, int nthreads, int reading,
+                                        uint64_t hist[4], uint32_t *max_ulp, int64_t *first_over_1ulp)
+{
+    return compare_generated(p, delays, dt, nt, c0, nc, got, 1, nthreads, reading, hist, max_ulp, first_over_1ulp);
 }
 
 /* BeamformerKernels.cu:153-177 (kernel a3's arithmetic), on the host. */

@@ -140,6 +140,14 @@ double dcs_oracle_compare_generated(const struct dcs_oracle_params *p,
                                     const float *dt, size_t nt, size_t c0, size_t nc,
                                     const float *got, int nthreads, int reading,
                                     uint64_t hist[4], uint32_t *max_ulp, int64_t *first_over_1ulp);
+/* The same for the packed binary16 output ([..][A*B] half2 = {re, im}): expectation RN-even(verifier's fp32)
+ * (dcs_oracle_f32_to_f16_rn), distances in binary16 ulps.  The reference emits this mode
+ * (BeamformerKernels.cu:113-115, 182-184) and never checks it (BeamformerCoefficientTest.cu:282-287). */
+double dcs_oracle_compare_generated_f16(const struct dcs_oracle_params *p,
+                                        const struct dcs_oracle_delay_vals *delays,
+                                        const float *dt, size_t nt, size_t c0, size_t nc,
+                                        const uint16_t *got, int nthreads, int reading,
+                                        uint64_t hist[4], uint32_t *max_ulp, int64_t *first_over_1ulp);
 
 /* Restatement of the reference's DEVICE arithmetic, kernel a3
  * (BeamformerKernels.cu:153-177): dt = t*Ts*FFT in fp32, integer

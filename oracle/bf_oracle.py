@@ -76,6 +76,8 @@ def lib() -> ctypes.CDLL:
         L.dcs_oracle_compare_generated.argtypes = [P, c_void_p, c_void_p, c_size_t, c_size_t, c_size_t, c_void_p, c_int, c_int,
                                                    POINTER(c_uint64 * 4), POINTER(c_uint32), POINTER(c_int64)]
         L.dcs_oracle_compare_generated.restype = c_double
+        L.dcs_oracle_compare_generated_f16.argtypes = L.dcs_oracle_compare_generated.argtypes
+        L.dcs_oracle_compare_generated_f16.restype = c_double
         L.dcs_oracle_compare.argtypes = [c_void_p, c_void_p, c_size_t, c_float]
         L.dcs_oracle_compare.restype = c_int64
         L.dcs_oracle_ulp_diff.argtypes = [c_float, c_float]
@@ -179,17 +181,19 @@ def generate_at(p: OracleParams, delays: np.ndarray, current_times, reference_ti
 
 
 def compare_generated(p: OracleParams, delays: np.ndarray, dt, c0: int, nc: int, got: np.ndarray, nthreads: int = 1, reading: int = 0):
-    """Every element of ``got`` ([nt][nc][A][B][2] fp32, C-contiguous; any buffer of that many floats) against
+    """Every element of ``got`` ([nt][nc][A][B][2] fp32 -- or uint16 binary16 patterns -- C-contiguous) against
     the verifier, generated on the fly over ``nthreads`` threads.  Returns dict(hist=[n0, n1, n2, n_more],
     max_ulp, first_over_1ulp, seconds)."""
     dt = np.ascontiguousarray(np.atleast_1d(np.asarray(dt, dtype=np.float32)))
     delays = np.ascontiguousarray(delays, dtype=delay_vals_dtype)
-    assert got.dtype == np.float32 and got.flags["C_CONTIGUOUS"]
+    assert got.dtype in (np.float32, np.uint16) and got.flags["C_CONTIGUOUS"]
     assert got.size == dt.size * nc * p.nr_stations * p.nr_beams * 2
     hist = (c_uint64 * 4)()
     mx = c_uint32(0)
     first = c_int64(-1)
-    secs = lib().dcs_oracle_compare_generated(byref(p), c_void_p(delays.ctypes.data), c_void_p(dt.ctypes.data), dt.size, int(c0), int(nc),
+    # uint16: the packed binary16 output; expectation RN-even(verifier's fp32), distances in binary16 ulps
+    fn = lib().dcs_oracle_compare_generated if got.dtype == np.float32 else lib().dcs_oracle_compare_generated_f16
+    secs = fn(byref(p), c_void_p(delays.ctypes.data), c_void_p(dt.ctypes.data), dt.size, int(c0), int(nc),
                                               c_void_p(got.ctypes.data), int(nthreads), int(reading), byref(hist), byref(mx), byref(first))
     return dict(hist=[int(v) for v in hist], max_ulp=int(mx.value), first_over_1ulp=int(first.value), seconds=float(secs))
 

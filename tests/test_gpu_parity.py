@@ -66,18 +66,19 @@ def _check_float_reading(oracle, got, op, table, t0, nt, limit=1):
     return mx
 
 
-def _compare_every_element(gpu, oracle, d_buf, op, table, dt, nc_total, n_pairs, readings=(0, 1), slab_bytes=1 << 30):
+def _compare_every_element(gpu, oracle, d_buf, op, table, dt, nc_total, n_pairs, readings=(0, 1), slab_bytes=1 << 30, half=False):
     """verify_output at full size (BeamformerCoefficientTest.cu:348-357 compares EVERY element): the device tensor
     [nc_total][n_pairs][2] fp32 of ONE time step comes back in <= 1 GiB slabs through a pinned buffer and each slab
     is compared with the verifier generated on the fly over all host cores (oracle.compare_generated).  Returns
-    {reading: dict(hist, max_ulp, first_over_1ulp, seconds)} accumulated over the slabs."""
+    {reading: dict(hist, max_ulp, first_over_1ulp, seconds)} accumulated over the slabs.  ``half``: the packed binary16
+    output, compared as bit patterns with RN-even(verifier's fp32), distances in binary16 ulps."""
     import os
     import time
 
-    row = n_pairs * 8
+    row = n_pairs * (4 if half else 8)
     per = max(1, slab_bytes // row)
     nthreads = max(1, min(64, len(os.sched_getaffinity(0))))
-    pinned = gpu.pagelocked_empty(per * n_pairs * 2, np.float32)
+    pinned = gpu.pagelocked_empty(per * n_pairs * 2, np.uint16 if half else np.float32)
     tot = {r: dict(hist=[0, 0, 0, 0], max_ulp=0, first_over_1ulp=-1, seconds=0.0) for r in readings}
     t_copy = 0.0
     for c0 in range(0, nc_total, per):
@@ -443,6 +444,50 @@ def test_config3_full_size_every_element(gpu, oracle, probes, record_property):
     gpu.memcpy_dtoh(small, buf)
     cks, _ = probes.tensor_properties(buf, small.nbytes)
     assert cks == oracle.checksum_of(small)
+    g.close()
+    buf.free()
+
+
+@pytest.mark.parametrize("math_mode", [0, 4])
+def test_config3_full_size_fp16_every_element(gpu, oracle, record_property, math_mode):
+    """The packed binary16 output of config 3 at FULL size (2^32 halves, 8 GiB), EVERY element against
+    RN-even(verifier's fp32) -- the check the reference never makes (BeamformerCoefficientTest.cu:282-287 skip the b16
+    case).  Default arithmetic (the <= 1 ULP fp32 pair rounded once): a half differs from the expectation only where the
+    fp32 value sits within its own last place of a binary16 rounding boundary -- at most 1 binary16 ulp, and rarely.  The
+    opt-in b16 arithmetic form (math_mode 4): within 1 binary16 ulp everywhere (tests/test_numerics.py proves that per
+    argument; this is the whole tensor)."""
+    import time
+
+    from dc_sand_amd import BeamformerParameters
+    from dc_sand_amd._lib import B16
+    from dc_sand_amd.generator import SteeringCoefficientGenerator, delta_times
+
+    bp = BeamformerParameters(NR_CHANNELS=32768, NR_STATIONS=64, NR_BEAMS=1024)
+    op = oracle.params_from(bp)
+    table = rand_table(bp.n_pairs)
+    g = SteeringCoefficientGenerator(bp)
+    g.upload_delays(table)
+    if math_mode:
+        g.set_tuning(math_mode=math_mode)
+    nbytes = g.output_bytes(B16, 1)
+    assert nbytes == 8 * 2 ** 30
+    buf = gpu.mem_alloc(nbytes)
+    t = 9
+    g.generate(buf, nbytes, t0=t, nt=1, bitwidth=B16)
+    gpu.synchronize()
+    t0 = time.perf_counter()
+    res = _compare_every_element(gpu, oracle, buf, op, table, delta_times(bp, t, 1)[0], bp.NR_CHANNELS, bp.n_pairs, readings=(0,), half=True)
+    wall = time.perf_counter() - t0
+    n = bp.NR_CHANNELS * bp.n_pairs * 2
+    h = res[0]["hist"]
+    assert sum(h) == n == 2 ** 32, "sampled fraction must be 1.0"
+    assert h[2] == 0 and h[3] == 0 and res[0]["max_ulp"] <= 1, res[0]
+    if math_mode == 0:
+        assert h[1] < n // 1000  # double rounding only: a few in 10^4
+    summary = (f"config 3 fp16 (math_mode {math_mode}), all {n} halves: {h[1]} at 1 binary16 ulp of RN16(verifier), 0 beyond; "
+               f"{wall:.1f} s wall on {res['threads']} threads (D2H {res['copy_seconds']:.1f} s)")
+    print(summary)
+    record_property("config3_fp16_full_compare", summary)
     g.close()
     buf.free()
 
