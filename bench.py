@@ -106,6 +106,24 @@ def cpu_baseline(bp, table, seconds: float) -> dict:
             s2, _ = orc.generate_checksum(op, table, 1, 1, 0, nc_mt, nt_threads)
         out["all_cores"] = {"value": nc_mt * n_pairs / s2 / 1e9, "cores": nt_threads,
                             "sample": f"channels [0,{nc_mt}) in {s2:.2f} s"}
+    # the verifier's beamformer with the coefficient of one time held for 256 samples (what
+    # also_measured.beamform_accumulated runs on the GPU), serial, on a bounded sample of the 64 x 16 shape
+    import time as _time
+
+    from dc_sand_amd import BeamformerParameters
+    from dc_sand_amd.generator import simulate_input
+
+    A, B, nt = 64, 16, 256
+    C = max(1, int(min(1024, 550 * seconds / 12.0)))  # ~1 s at the default --cpu-seconds
+    fp = BeamformerParameters(NR_CHANNELS=C, NR_STATIONS=A, NR_BEAMS=B, NR_SAMPLES_PER_CHANNEL=nt)
+    fop = orc.params_from(fp)
+    ant = orc.simulate_antenna_data(fop, nt)
+    t0 = _time.perf_counter()
+    with orc.trig_reading(orc.FLOAT_LIBM):
+        orc.beamform_accumulated(fop, simulate_input(fp), np.float32(0.0008192), nt, ant)
+    sb = _time.perf_counter() - t0
+    out["beamform_accumulated"] = {"value": A * B * C * nt / sb / 1e9, "unit": "T coefficient-products/s", "cores": 1, "kind": "port",
+                                   "sample": f"{A}ant x {B}beam x {C}chan x {nt}samples in {sb:.2f} s, 1 thread"}
     return out
 
 

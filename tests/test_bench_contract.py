@@ -77,6 +77,7 @@ def test_single_gpu_line_with_cpu_baseline():
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] == 1 and c["unit"] == "Gcoeff/s" and c["value"] > 0 and c["sample"]
     assert c["gpu_vs_oracle_spot_check"]["over_1ulp"] == 0
+    assert c["beamform_accumulated"]["value"] > 0 and c["beamform_accumulated"]["cores"] == 1
 
 
 def test_collective_control_flow_over_rccl_world_of_one():
