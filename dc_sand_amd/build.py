@@ -56,17 +56,40 @@ def needs_build() -> bool:
     return any(d.resolve().stat().st_mtime > t for d in deps)
 
 
+def compile_and_link(sources, extra_flags, out: Path, verbose: bool = False) -> None:
+    """One ``hipcc -c`` per source, side by side (the translation units are independent: no -fgpu-rdc), then one
+    link.  The objects live in a temporary directory; only ``out`` is left in the tree."""
+    import tempfile
+    from concurrent.futures import ThreadPoolExecutor
+
+    hipcc = _hipcc()
+    with tempfile.TemporaryDirectory(prefix="dcs_build_") as tmp:
+        def one(src):
+            obj = Path(tmp) / (Path(src).stem + ".o")
+            cmd = [hipcc, *flags(), *extra_flags, "-c", str(src), "-o", str(obj)]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            res = subprocess.run(cmd, capture_output=True, text=True)
+            if res.returncode != 0:
+                raise RuntimeError(f"hipcc failed ({res.returncode}) on {src}:\n{res.stdout}\n{res.stderr}")
+            if verbose and res.stderr.strip():
+                print(res.stderr, file=sys.stderr)
+            return obj
+
+        with ThreadPoolExecutor(max_workers=min(4, len(sources))) as pool:
+            objs = list(pool.map(one, sources))
+        cmd = [hipcc, f"--offload-arch={ARCH}", "-fPIC", "-shared", "-o", str(out), *[str(o) for o in objs]]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        res = subprocess.run(cmd, capture_output=True, text=True)
+        if res.returncode != 0:
+            raise RuntimeError(f"hipcc link failed ({res.returncode}):\n{res.stdout}\n{res.stderr}")
+
+
 def build(force: bool = False, verbose: bool = False) -> Path:
     if not force and not needs_build():
         return LIB
-    cmd = [_hipcc(), *flags(), "-shared", "-o", str(LIB), *[str(CSRC / s) for s in SOURCES]]
-    if verbose:
-        print(" ".join(cmd), flush=True)
-    res = subprocess.run(cmd, capture_output=True, text=True)
-    if res.returncode != 0:
-        raise RuntimeError(f"hipcc failed ({res.returncode}):\n{res.stdout}\n{res.stderr}")
-    if verbose and res.stderr.strip():
-        print(res.stderr, file=sys.stderr)
+    compile_and_link([CSRC / s for s in SOURCES], [], LIB, verbose)
     return LIB
 
 

@@ -25,14 +25,7 @@ def needs_build() -> bool:
 def build(force: bool = False, verbose: bool = False) -> Path:
     if not force and not needs_build():
         return LIB
-    cmd = [product._hipcc(), *product.flags(), "-DDCS_PROBES", "-shared", "-o", str(LIB), *[str(s) for s in SOURCES]]
-    if verbose:
-        print(" ".join(cmd), flush=True)
-    res = subprocess.run(cmd, capture_output=True, text=True)
-    if res.returncode != 0:
-        raise RuntimeError(f"hipcc failed ({res.returncode}):\n{res.stdout}\n{res.stderr}")
-    if verbose and res.stderr.strip():
-        print(res.stderr, file=sys.stderr)
+    product.compile_and_link(SOURCES, ["-DDCS_PROBES"], LIB, verbose)
     return LIB
 
 
