@@ -201,8 +201,8 @@ __global__ void __launch_bounds__(kBlock) bf_beamform_acc_kernel(const bf_bacc_a
 // A wave owns one 16-beam tile of one channel and some of the workgroup's 16-sample blocks.  Its coefficients
 // (64 antennas = 6 operands of 4 registers: 3 digits x {re, im}) are made once, in registers (waves that own the
 // same tile make a share each and exchange them through LDS).  Up to 64 antennas the workgroup's sample blocks
-// (at most 16 = 32 KiB) travel to LDS by LDS-DMA while the coefficients are being made; beyond, a wave loads its
-// operands itself, two load sets in flight.  Per pair of blocks and 64 antennas: 16 four-byte operand reads per
+// (at most 16 = 32 KiB) travel to LDS by LDS-DMA while the coefficients are being made; beyond, the antennas are
+// split over the workgroup's waves (64 each), which load their own operands and add their partial sums up in LDS.  Per pair of blocks and 64 antennas: 16 four-byte operand reads per
 // lane, a 4 x 4 byte transpose into four K = 64 operands (slot (lane >> 4, byte p) of BOTH operands is antenna
 // 64 ch + 4 p + (lane >> 4): the contraction index may be permuted freely as long as both sides agree), 12 MFMAs,
 // ~130 vector instructions to recombine, 4 sixteen-byte stores.  The arithmetic is hidden entirely: with its stores
@@ -220,17 +220,28 @@ __device__ __forceinline__ uint32_t fixed_word(float w)
     return ((uint32_t)(int)rintf(f) + 0x808080u) ^ 0x808080u;
 }
 
-// NCH = 1, 2 or 4 chunks of 64 antennas; FULL: nr_stations == 64 * NCH; STAGED (NCH == 1): the workgroup's sample blocks
-// (at most 16: 32 KiB) travel to LDS by LDS-DMA, all at once and while the coefficients are being made, and the waves
-// read their operands from there -- every wave of the workgroup needs the same blocks when it owns several beam tiles,
-// and no wave ever waits for a global load inside its loop (a wave that loads its own operands pays one memory
-// latency per trip; with loads and stores but no arithmetic that form ran exactly as fast as with the arithmetic).
-template <int NCH, bool FULL, bool STAGED>
-__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(NCH == 1 ? (FULL ? 4 : 3) : (NCH == 2 ? 2 : 1))))
+// Three forms of one kernel (FORM):
+//   kStaged (nr_stations <= 64): the workgroup's sample blocks (at most 16: 32 KiB) travel to LDS by LDS-DMA, all at
+//       once and while the coefficients are being made, and the waves read their operands from there -- every wave of
+//       the workgroup needs the same blocks when it owns several beam tiles, and no wave ever waits for a global load
+//       inside its loop (a wave that loads its own operands pays one memory latency per trip; with loads and stores
+//       but no arithmetic that form ran exactly as fast as with the arithmetic).  Wave w: beam tile w % nbt, blocks
+//       w / nbt, w / nbt + 4 / nbt, ...
+//   kDirect (nr_stations <= 64; probes and A/B only): the same, every wave loading its own operands.
+//   kSplit  (64 < nr_stations <= 256): the CONTRACTION INDEX is split over the waves -- wave w holds the coefficients
+//       of antennas [64 w, 64 w + 64) of the workgroup's ONE beam tile (24 registers, as in the other forms, instead of
+//       96 in one wave), loads that chunk's operands itself, and the four partial sums of a pair of blocks meet in
+//       LDS: each wave adds up, scales and stores the four beams of one result register (wave w: beams w, w + 4 ... of
+//       the tile).  Two barriers per trip of two pairs.
+// FULL: nr_stations is a multiple of 64 (no antenna masks, immediate load offsets).
+enum { kStaged = 0, kDirect = 1, kSplit = 2 };
+
+template <int FORM, bool FULL>
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(FORM == kSplit ? (FULL ? 3 : 2) : (FULL || FORM == kStaged ? 4 : 3))))
 bf_beamform_i8_kernel(const bf_bacc_args a)
 {
-    static_assert(!STAGED || NCH == 1, "the staged form holds one 64-antenna chunk");
-    extern __shared__ __attribute__((aligned(16))) char staged[];
+    constexpr bool STAGED = FORM == kStaged, SPLIT = FORM == kSplit;
+    extern __shared__ __attribute__((aligned(16))) char staged[]; // kStaged: the sample image (+ the coefficient exchange); kSplit: the partial sums
     uint32_t bid = blockIdx.x;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t lane = threadIdx.x & 63u;
@@ -238,15 +249,19 @@ bf_beamform_i8_kernel(const bf_bacc_args a)
     bid /= a.n_bgroups;
     const uint32_t tg = bid % a.n_tgroups;
     const uint32_t c = bid / a.n_tgroups;
-    const uint32_t nbt = 1u << a.nbt_log2, tpr = 4u >> a.nbt_log2; // beam tiles per workgroup, sample blocks per round
-    const uint32_t bt = wave & (nbt - 1u), slot = wave >> a.nbt_log2;
+    // beam tiles per workgroup, sample blocks per round (kSplit: one tile, every wave takes every block)
+    const uint32_t nbt_log2 = SPLIT ? 0u : a.nbt_log2;
+    const uint32_t nbt = 1u << nbt_log2, tpr = SPLIT ? 1u : 4u >> nbt_log2;
+    const uint32_t bt = SPLIT ? 0u : wave & (nbt - 1u), slot = SPLIT ? 0u : wave >> nbt_log2;
+    const uint32_t kc = SPLIT ? wave : 0u;         // this wave's 64-antenna chunk
     const uint32_t lm = lane & 15u, lg = lane >> 4;
     const uint32_t bw = (bg * nbt + bt) * 16u;     // first beam of this wave's tile
     const uint32_t tt0 = tg * a.tiles_per_wg;      // first 16-sample block of the workgroup
     const uint32_t tt1 = min(tt0 + a.tiles_per_wg, a.nT16);
     const uint32_t n_blocks = tt1 > tt0 + slot ? (tt1 - tt0 - slot + tpr - 1u) / tpr : 0u; // this wave's sample blocks
-    const bool idle = bw >= a.B || n_blocks == 0u; // wave-uniform
-    if (!STAGED && idle) return;                   // (no barrier in the unstaged form)
+    const bool idle = bw >= a.B || n_blocks == 0u; // wave-uniform (kSplit: workgroup-uniform)
+    if (!STAGED && idle) return;                   // (no barrier behind this in the direct form; all waves alike in kSplit)
+    const bool has_chunk = !SPLIT || 64u * kc < a.A; // kSplit with <= 192 antennas: the last wave(s) only add and store
     if (STAGED) { // this wave's share of the workgroup's blocks: global -> LDS, 1 KiB per instruction, same byte order
         typedef __attribute__((address_space(3))) void lds_void;
         typedef const __attribute__((address_space(1))) void glb_void;
@@ -261,21 +276,17 @@ bf_beamform_i8_kernel(const bf_bacc_args a)
     const float fChan = (float)c;
     const float D = a.k.fDenominator, y = a.k.fRcpDenominator;
 
-    // ---- coefficients: lane (beam lm, group lg) holds, in byte p of operand (ch, digit), antenna 64 ch + 4 p + lg.
-    //      Per chunk: 16 terms loads in flight together, then four rolled trips of four antennas each: a trip makes one
-    //      whole register of each of the six operands, which enters at the top while the others move down (after four
-    //      trips register q holds antennas 4 (4 q .. 4 q + 3) + lg), and the loaded terms move down by four likewise --
-    //      no register is ever indexed by a loop variable.
-    // STAGED, fewer than four beam tiles per workgroup: the 4 / nbt waves that own the same tile make a quarter (half)
+    // ---- coefficients: lane (row lm, group lg) holds, in byte p of each of its six operands (3 digits x {re, im}),
+    //      antenna 64 kc + 4 p + lg.  16 terms loads in flight together; the fast classes fully unrolled (16 copies of
+    //      ~34 instructions, nothing moves), the slow class in four rolled trips.
+    // kStaged, fewer than four beam tiles per workgroup: the 4 / nbt waves that own the same tile make a quarter (half)
     // of its coefficient registers each and exchange them through LDS behind the staging barrier (the slow class makes
     // everything everywhere: its rolled loop does not split)
     const bool shared_w = STAGED && a.share_off != 0u && tpr > 1u && cls != DCS_CLASS_SLOW;
-    intx4 wre[NCH][3], wim[NCH][3];
+    intx4 wre[3], wim[3];
 #pragma unroll
-    for (int ch = 0; ch < NCH; ch++)
-#pragma unroll
-        for (int d = 0; d < 3; d++) wre[ch][d] = wim[ch][d] = intx4{0, 0, 0, 0};
-    auto make_coefficients = [&](intx4 (&wre)[NCH][3], intx4 (&wim)[NCH][3]) {
+    for (int d = 0; d < 3; d++) wre[d] = wim[d] = intx4{0, 0, 0, 0};
+    auto make_coefficients = [&]() {
         // row i of the result tile is beam 4 (i & 3) + (i >> 2): the four lane groups of a store instruction then
         // hold four CONSECUTIVE beams (512 contiguous bytes per block) instead of every fourth
         const uint32_t beam = bw + 4u * (lm & 3u) + (lm >> 2);
@@ -289,8 +300,8 @@ bf_beamform_i8_kernel(const bf_bacc_args a)
             out[1] = __builtin_amdgcn_perm(t2, t0, 0x07060302u); // bytes 1: d2
             out[0] = __builtin_amdgcn_perm(t3, t1, 0x05040100u); // bytes 2: d1
         };
-        // antennas 4 (4 q + z) + lg, z = 0..3, of chunk ch from their terms: one register of each of the six operands
-        auto four = [&](auto gen, int ch, uint32_t q, const floatx2 (&k4)[4], uint32_t (&nr)[3], uint32_t (&ni)[3]) {
+        // antennas 64 kc + 4 (4 q + z) + lg, z = 0..3, from their terms: one register of each of the six operands
+        auto four = [&](auto gen, uint32_t q, const floatx2 (&k4)[4], uint32_t (&nr)[3], uint32_t (&ni)[3]) {
             uint32_t gr[4], gi[4];
 #pragma unroll
             for (uint32_t z = 0; z < 4; z++) {
@@ -302,53 +313,47 @@ bf_beamform_i8_kernel(const bf_bacc_args a)
             if (!FULL) { // antennas beyond nr_stations: zero digits, byte by byte
                 uint32_t mask = 0;
 #pragma unroll
-                for (uint32_t z = 0; z < 4; z++) mask |= 64u * ch + 4u * (4u * q + z) + lg < a.A ? 0xffu << (8u * z) : 0u;
+                for (uint32_t z = 0; z < 4; z++) mask |= 64u * kc + 4u * (4u * q + z) + lg < a.A ? 0xffu << (8u * z) : 0u;
 #pragma unroll
                 for (int d = 0; d < 3; d++) nr[d] &= mask, ni[d] &= mask;
             }
         };
         auto generate = [&](auto gen, auto unrolled) {
+            floatx2 kp[16];
 #pragma unroll
-            for (int ch = 0; ch < NCH; ch++) {
-                floatx2 kp[16];
+            for (uint32_t z = 0; z < 16; z++) {
+                const uint32_t ant = 64u * kc + 4u * z + lg;
+                kp[z] = *reinterpret_cast<const floatx2 *>(tp + 2u * (uint64_t)min(ant, a.A - 1u) * a.B);
+            }
+            if (decltype(unrolled)::value) {
 #pragma unroll
-                for (uint32_t z = 0; z < 16; z++) {
-                    const uint32_t ant = 64u * ch + 4u * z + lg;
-                    kp[z] = *reinterpret_cast<const floatx2 *>(tp + 2u * (uint64_t)min(ant, a.A - 1u) * a.B);
+                for (uint32_t q = 0; q < 4; q++) {
+                    if (shared_w && (q & (tpr - 1u)) != slot) continue; // a wave sharing its tile makes its own registers only
+                    const floatx2 k4[4] = {kp[4 * q], kp[4 * q + 1], kp[4 * q + 2], kp[4 * q + 3]};
+                    uint32_t nr[3], ni[3];
+                    four(gen, q, k4, nr, ni);
+#pragma unroll
+                    for (int d = 0; d < 3; d++) wre[d][q] = (int)nr[d], wim[d][q] = (int)ni[d];
                 }
-                if (decltype(unrolled)::value) { // the fast classes: 16 copies of ~34 instructions, nothing moves
-#pragma unroll
-                    for (uint32_t q = 0; q < 4; q++) {
-                        if (shared_w && (q & (tpr - 1u)) != slot) continue; // a wave sharing its tile makes its own registers only
-                        const floatx2 k4[4] = {kp[4 * q], kp[4 * q + 1], kp[4 * q + 2], kp[4 * q + 3]};
-                        uint32_t nr[3], ni[3];
-                        four(gen, ch, q, k4, nr, ni);
-#pragma unroll
-                        for (int d = 0; d < 3; d++) wre[ch][d][q] = (int)nr[d], wim[ch][d][q] = (int)ni[d];
-                    }
-                } else { // the slow class (fp64 sincos): four rolled trips; the new register enters at the top while the
-                         // others, and the loaded terms, move down -- no register is indexed by a loop variable
-#pragma unroll
-                    for (int d = 0; d < 3; d++) wre[ch][d] = intx4{0, 0, 0, 0}, wim[ch][d] = intx4{0, 0, 0, 0};
+            } else { // the new register enters at the top while the others, and the loaded terms, move down -- no
+                     // register is indexed by a loop variable
 #pragma unroll 1
-                    for (uint32_t q = 0; q < 4; q++) {
-                        const floatx2 k4[4] = {kp[0], kp[1], kp[2], kp[3]};
-                        uint32_t nr[3], ni[3];
-                        four(gen, ch, q, k4, nr, ni);
+                for (uint32_t q = 0; q < 4; q++) {
+                    const floatx2 k4[4] = {kp[0], kp[1], kp[2], kp[3]};
+                    uint32_t nr[3], ni[3];
+                    four(gen, q, k4, nr, ni);
 #pragma unroll
-                        for (int d = 0; d < 3; d++) {
-                            wre[ch][d] = intx4{wre[ch][d][1], wre[ch][d][2], wre[ch][d][3], (int)nr[d]};
-                            wim[ch][d] = intx4{wim[ch][d][1], wim[ch][d][2], wim[ch][d][3], (int)ni[d]};
-                        }
-#pragma unroll
-                        for (uint32_t z = 0; z < 12; z++) kp[z] = kp[z + 4];
+                    for (int d = 0; d < 3; d++) {
+                        wre[d] = intx4{wre[d][1], wre[d][2], wre[d][3], (int)nr[d]};
+                        wim[d] = intx4{wim[d][1], wim[d][2], wim[d][3], (int)ni[d]};
                     }
-                }
-                if (!beam_live) { // beams beyond nr_beams: zero coefficients (their results are not stored either)
 #pragma unroll
-                    for (int d = 0; d < 3; d++) wre[ch][d] = intx4{0, 0, 0, 0}, wim[ch][d] = intx4{0, 0, 0, 0};
+                    for (uint32_t z = 0; z < 12; z++) kp[z] = kp[z + 4];
                 }
-                __builtin_amdgcn_sched_barrier(0); // one chunk's 16 terms loads (32 registers) at a time
+            }
+            if (!beam_live) { // beams beyond nr_beams: zero coefficients (their results are not stored either)
+#pragma unroll
+                for (int d = 0; d < 3; d++) wre[d] = wim[d] = intx4{0, 0, 0, 0};
             }
         };
         if (cls == DCS_CLASS_SLOW) {
@@ -369,14 +374,13 @@ bf_beamform_i8_kernel(const bf_bacc_args a)
     //      antennas) turns 16 loaded registers into the 4 K = 64 operands; a result lane holds samples 2 m and 2 m + 1 of
     //      its 4 beams: one 16-byte store each.  Half the load and store instructions of a per-block scheme and no
     //      half-word merging (d16 loads do not keep the other half with SRAM-ECC on).
-    //      Addresses: a wave-uniform base (scalar registers) plus a per-lane byte offset; with whole chunks (FULL) ONE
-    //      offset register and the instruction's immediate (antenna 4 p + lg is 128 p bytes further), otherwise offsets
-    //      clamped to the last antenna (the coefficient digits are 0 beyond nr_stations).
-    //      Two load sets (pairs, or chunks of one pair) are in flight per wave.  hipcc waits for ALL memory operations
-    //      at the head of a loop whose loads cross the back-edge, stores included, so the order inside a trip is: wait,
-    //      transpose, MFMAs, STORES, then the next trip's LOADS -- one memory latency per trip, shared by loads and
-    //      stores (with the loads issued first, each trip paid the load and the store latency one after the other:
-    //      3.2 us per block and wave, 40-60 % of the HBM rate; a block's arithmetic is ~0.2 us).
+    //      Global addresses (kDirect, kSplit): a wave-uniform base (scalar registers) plus a per-lane byte offset; with
+    //      whole chunks (FULL) ONE offset register and the instruction's immediate (antenna 4 p + lg is 128 p bytes
+    //      further), otherwise offsets clamped to the last antenna (the coefficient digits are 0 beyond nr_stations).
+    //      Two load sets are in flight per wave.  hipcc waits for ALL memory operations at the head of a loop whose
+    //      loads cross the back-edge, stores included, so the order inside a trip is: wait, transpose, MFMAs, STORES,
+    //      then the next trip's LOADS -- one memory latency per trip, shared by loads and stores (with the loads issued
+    //      first, each trip paid the load and the store latency one after the other: 3.2 us per block and wave).
     const char *ant8 = reinterpret_cast<const char *>(a.ant);
     const uint32_t blk_bytes = a.A * 32u;            // one 16-sample block of one channel: <= 8 KiB
     const uint32_t m = lm & 7u;
@@ -389,7 +393,7 @@ bf_beamform_i8_kernel(const bf_bacc_args a)
         asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]));
         asm volatile("" : "+v"(v[8]), "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15]));
     };
-    auto fetch = [&](uint32_t (&dst)[16], uint32_t blk, uint32_t ch) { // pair (blk, min(blk + 1, last)), chunk ch
+    auto fetch = [&](uint32_t (&dst)[16], uint32_t blk) { // pair (blk, min(blk + 1, last)), this wave's chunk
         const uint32_t blkA = min(blk, last), blkB = min(blk + 1u, last);
         if (STAGED) { // from the LDS image: block j of the workgroup at j * blk_bytes
             const uint32_t at = ((second ? blkB : blkA) * tpr + slot) * blk_bytes + m * 4u;
@@ -401,14 +405,14 @@ bf_beamform_i8_kernel(const bf_bacc_args a)
         const char *base = ant8 + ((uint64_t)c * a.nT16 + tt0 + blkA * tpr + slot) * blk_bytes; // wave-uniform
         const uint32_t hop = second ? (blkB - blkA) * tpr * blk_bytes : 0u;
         if (FULL) {
-            const char *b2 = base + 2048u * ch;
+            const char *b2 = base + 2048u * kc;
             const uint32_t vo = hop + voff;
 #pragma unroll
             for (uint32_t p = 0; p < 16; p++) dst[p] = *reinterpret_cast<const uint32_t *>(b2 + vo + 128u * p);
         } else {
 #pragma unroll
             for (uint32_t p = 0; p < 16; p++)
-                dst[p] = *reinterpret_cast<const uint32_t *>(base + (hop + min(64u * ch + lg + 4u * p, a.A - 1u) * 32u + m * 4u));
+                dst[p] = *reinterpret_cast<const uint32_t *>(base + (hop + min(64u * kc + lg + 4u * p, a.A - 1u) * 32u + m * 4u));
         }
     };
     // x[0] = re of the even samples, x[1] = im even, x[2] = re odd, x[3] = im odd; byte p of each = antenna 4 p + lg
@@ -425,60 +429,79 @@ bf_beamform_i8_kernel(const bf_bacc_args a)
             x[3][q] = (int)__builtin_amdgcn_perm(t3, t1, 0x07060302u);
         }
     };
-    // One load set (64 antennas of a pair of blocks) into the running fp32 sums f[v], plane v = (re even, im even,
-    // re odd, im odd): three integer contractions from zero per plane, each exact (|sum| < 2^21); the two low digits are
-    // combined in integers (s2 * 256 + s3 < 2^29: exact), converted (one rounding, far below the result's last place),
-    // and the high digit enters with one fma.
+    // One load set (64 antennas of a pair of blocks) as fp32 sums f[v], plane v = (re even, im even, re odd, im odd):
+    // three integer contractions from zero per plane, each exact (|sum| <= 2^20); the two low digits are combined in
+    // integers (s2 * 256 + s3 < 2^29: exact), converted (one rounding, far below the result's last place), and the
+    // high digit enters with one fma.
     const intx4 zero = {0, 0, 0, 0};
-    auto contract = [&](int ch, const intx4 (&x)[4], floatx4 (&f)[4], bool first) {
+    auto contract = [&](const intx4 (&x)[4], floatx4 (&f)[4]) {
 #pragma unroll
         for (int v = 0; v < 4; v++) {
-            const intx4 s3 = __builtin_amdgcn_mfma_i32_16x16x64_i8((v & 1) ? wim[ch][2] : wre[ch][2], x[v], zero, 0, 0, 0);
-            const intx4 s2 = __builtin_amdgcn_mfma_i32_16x16x64_i8((v & 1) ? wim[ch][1] : wre[ch][1], x[v], zero, 0, 0, 0);
-            const intx4 s1 = __builtin_amdgcn_mfma_i32_16x16x64_i8((v & 1) ? wim[ch][0] : wre[ch][0], x[v], zero, 0, 0, 0);
+            const intx4 s3 = __builtin_amdgcn_mfma_i32_16x16x64_i8((v & 1) ? wim[2] : wre[2], x[v], zero, 0, 0, 0);
+            const intx4 s2 = __builtin_amdgcn_mfma_i32_16x16x64_i8((v & 1) ? wim[1] : wre[1], x[v], zero, 0, 0, 0);
+            const intx4 s1 = __builtin_amdgcn_mfma_i32_16x16x64_i8((v & 1) ? wim[0] : wre[0], x[v], zero, 0, 0, 0);
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const float lo = (float)(s2[r] * 256 + s3[r]);
-                const float t = fmaf((float)s1[r], 65536.0f, lo);
-                f[v][r] = first ? t : f[v][r] + t;
-            }
+            for (int r = 0; r < 4; r++) f[v][r] = fmaf((float)s1[r], 65536.0f, (float)(s2[r] * 256 + s3[r]));
         }
     };
     const float inv = 1.0f / kFixScale;
     const uint32_t bb = bw + lg;         // register r of this lane: beam bb + 4 r
     const uint32_t out_blk = a.B * 128u; // bytes per 16-sample block of one channel
     char *out8 = reinterpret_cast<char *>(a.beams);
-    // scale and store: lane l, register r = beam bw + (l >> 4) + 4 r, samples 2 m, 2 m + 1
-    auto finish = [&](auto whole, uint32_t blk, const floatx4 (&f)[4]) {
+    // where this lane's 16 bytes {re, im} x samples (2 m, 2 m + 1) of beam bb + 4 r go, pair (blk, blk + 1)
+    auto out_of = [&](uint32_t blk, int r) {
         const uint32_t blkA = min(blk, last), blkB = min(blk + 1u, last);
         char *base = out8 + ((uint64_t)c * a.nT16 + tt0 + blkA * tpr + slot) * out_blk; // wave-uniform
-        const uint32_t vo = (second ? (blkB - blkA) * tpr * out_blk : 0u) + bb * 128u + m * 16u;
+        return reinterpret_cast<floatx4 *>(base + ((second ? (blkB - blkA) * tpr * out_blk : 0u) + bb * 128u + m * 16u + 512u * r));
+    };
+    auto store = [&](floatx4 *dst, const floatx4 o) {
+        if (a.plain_stores)
+            *dst = o;
+        else
+            __builtin_nontemporal_store(o, dst); // written once, read by another kernel: do not keep it in L2
+    };
+    // scale and store: lane l, register r = beam bw + (l >> 4) + 4 r, samples 2 m, 2 m + 1
+    auto finish = [&](auto whole, uint32_t blk, const floatx4 (&f)[4]) {
 #pragma unroll
         for (int r = 0; r < 4; r++) { // beam bb + 4 r
             const floatx4 o = {f[0][r] * inv, f[1][r] * inv, f[2][r] * inv, f[3][r] * inv};
             if (decltype(whole)::value || bb + 4u * r < a.B) {
-                floatx4 *dst = reinterpret_cast<floatx4 *>(base + (vo + 512u * r));
+                floatx4 *dst = out_of(blk, r);
 #ifdef DCS_PROBES
-                if (a.probe == 4u) // same bytes, but each instruction writes ONE contiguous KiB (values land in the wrong places)
-                    dst = reinterpret_cast<floatx4 *>(base + ((r >= 2 ? (blkB - blkA) * tpr * out_blk : 0u) + bw * 128u + (r & 1) * 1024u + lane * 16u));
+                if (a.probe == 4u) { // same bytes, but each instruction writes ONE contiguous KiB (values land in the wrong places)
+                    const uint32_t blkA = min(blk, last), blkB = min(blk + 1u, last);
+                    dst = reinterpret_cast<floatx4 *>(out8 + ((uint64_t)c * a.nT16 + tt0 + blkA * tpr + slot) * out_blk +
+                                                      ((r >= 2 ? (blkB - blkA) * tpr * out_blk : 0u) + bw * 128u + (r & 1) * 1024u + lane * 16u));
+                }
 #endif
-                if (a.plain_stores)
-                    *dst = o;
-                else
-                    __builtin_nontemporal_store(o, dst); // written once, read by another kernel: do not keep it in L2
+                store(dst, o);
             }
         }
     };
+    // kSplit: the partial sums of two pairs meet in LDS -- [pair h][register r][chunk][lane] x 16 bytes -- and wave w
+    // adds up (in chunk order), scales and stores register r = w
+    floatx4 *part = reinterpret_cast<floatx4 *>(staged);
+    const uint32_t n_chunks = (a.A + 63u) / 64u;
+    auto park = [&](int h, const floatx4 (&f)[4]) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) part[((h * 4 + r) * 4 + kc) * 64u + lane] = floatx4{f[0][r], f[1][r], f[2][r], f[3][r]};
+    };
+    auto gather = [&](auto whole, int h, uint32_t blk) {
+        floatx4 o = part[((h * 4 + wave) * 4 + 0) * 64u + lane];
+        for (uint32_t k = 1; k < n_chunks; k++) o = o + part[((h * 4 + wave) * 4 + k) * 64u + lane];
+        o = o * inv;
+        if (decltype(whole)::value || bb + 4u * wave < a.B) store(out_of(blk, (int)wave), o);
+    };
     auto run = [&](auto whole) {
 #ifdef DCS_PROBES
-        if (a.probe == 1u || a.probe == 3u || a.probe == 4u) { // stores only: what does the memory system make of this store pattern alone?
+        if (!SPLIT && (a.probe == 1u || a.probe == 3u || a.probe == 4u)) { // stores only: what does the memory system make of this store pattern alone?
             floatx4 f[4];
 #pragma unroll
-            for (int v = 0; v < 4; v++) f[v] = floatx4{(float)wre[0][0][0], (float)wre[0][1][1], (float)wim[0][0][2], (float)wim[0][2][3]};
+            for (int v = 0; v < 4; v++) f[v] = floatx4{(float)wre[0][0], (float)wre[1][1], (float)wim[0][2], (float)wim[2][3]};
             for (uint32_t blk = 0; blk < n_blocks; blk += 2) finish(whole, blk, f);
             return;
         }
-        if (a.probe == 2u) { // loads and stores, no arithmetic between them
+        if (FORM == kDirect && a.probe == 2u) { // loads and stores, no arithmetic between them
             for (uint32_t blk = 0; blk < n_blocks; blk += 4) {
                 arrived(cur[0]);
                 arrived(cur[1]);
@@ -491,8 +514,8 @@ bf_beamform_i8_kernel(const bf_bacc_args a)
                     finish(whole, blk + 2u * h, f);
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                fetch(cur[0], blk + 4u, 0);
-                fetch(cur[1], blk + 6u, 0);
+                fetch(cur[0], blk + 4u);
+                fetch(cur[1], blk + 6u);
             }
             return;
         }
@@ -501,62 +524,52 @@ bf_beamform_i8_kernel(const bf_bacc_args a)
             for (uint32_t blk = 0; blk < n_blocks; blk += 2) {
                 intx4 x[4];
                 floatx4 f[4];
-                fetch(cur[0], blk, 0);
+                fetch(cur[0], blk);
                 transpose(cur[0], x);
-                contract(0, x, f, true);
+                contract(x, f);
                 finish(whole, blk, f);
             }
-        } else if (NCH == 1) { // a trip = two pairs of sample blocks
+        } else { // a trip = two pairs of sample blocks (a pair past the end repeats the last block)
             for (uint32_t blk = 0; blk < n_blocks; blk += 4) {
-                arrived(cur[0]);
-                arrived(cur[1]);
-#pragma unroll
-                for (int h = 0; h < 2; h++) {
-                    intx4 x[4];
-                    floatx4 f[4];
-                    transpose(cur[h], x);
-                    contract(0, x, f, true);
-                    finish(whole, blk + 2u * h, f); // a pair past the end repeats the last block
-                }
-                __builtin_amdgcn_sched_barrier(0); // the loads stay behind the stores (see above)
-                fetch(cur[0], blk + 4u, 0);
-                fetch(cur[1], blk + 6u, 0);
-            }
-        } else { // a trip = two chunks of one pair
-            for (uint32_t blk = 0; blk < n_blocks; blk += 2) {
-                floatx4 f[4];
-#pragma unroll
-                for (int h = 0; h < NCH / 2; h++) {
+                if (has_chunk) {
                     arrived(cur[0]);
                     arrived(cur[1]);
 #pragma unroll
-                    for (int e = 0; e < 2; e++) {
+                    for (int h = 0; h < 2; h++) {
                         intx4 x[4];
-                        transpose(cur[e], x);
-                        contract(2 * h + e, x, f, h == 0 && e == 0);
+                        floatx4 f[4];
+                        transpose(cur[h], x);
+                        contract(x, f);
+                        if (SPLIT)
+                            park(h, f);
+                        else
+                            finish(whole, blk + 2u * h, f);
                     }
-                    if (h + 1 == NCH / 2) finish(whole, blk, f);
-                    const uint32_t nblk = h + 1 == NCH / 2 ? blk + 2u : blk;
-                    const uint32_t nch = h + 1 == NCH / 2 ? 0u : 2u * (h + 1);
-                    __builtin_amdgcn_sched_barrier(0); // the loads stay behind the stores (see above)
-                    fetch(cur[0], nblk, nch);
-                    fetch(cur[1], nblk, nch + 1u);
+                }
+                if (SPLIT) {
+                    __syncthreads(); // every chunk's partial sums are in LDS
+                    gather(whole, 0, blk);
+                    gather(whole, 1, blk + 2u);
+                    __syncthreads(); // ... and read, before the next trip overwrites them
+                }
+                __builtin_amdgcn_sched_barrier(0); // the loads stay behind the stores (see above)
+                if (has_chunk) {
+                    fetch(cur[0], blk + 4u);
+                    fetch(cur[1], blk + 6u);
                 }
             }
         }
     };
-    // the first trip's samples (STAGED: all of them) travel while the coefficients are made
-    if (!STAGED) fetch(cur[0], 0, 0);
+    // the first trip's samples (kStaged: all of them, above) travel while the coefficients are made
+    if (!STAGED && has_chunk) fetch(cur[0], 0);
     __builtin_amdgcn_sched_barrier(0);
 #ifdef DCS_PROBES
     if (a.probe == 3u || a.probe == 4u) { // no coefficients either: the store pattern alone
 #pragma unroll
-        for (int ch = 0; ch < NCH; ch++)
-#pragma unroll
-            for (int d = 0; d < 3; d++) wre[ch][d] = wim[ch][d] = intx4{(int)lane, d, ch, 1};
+        for (int d = 0; d < 3; d++) wre[d] = wim[d] = intx4{(int)lane, d, 2, 1};
     } else
 #endif
-    if (shared_w ? bw < a.B : !idle) make_coefficients(wre, wim);
+    if ((shared_w ? bw < a.B : !idle) && has_chunk) make_coefficients();
     if (STAGED) {
         uint32_t *wx = reinterpret_cast<uint32_t *>(staged + a.share_off) + bt * (4u * 6u * 64u) + lane; // [tile][q][plane][lane]
         if (shared_w && bw < a.B) {
@@ -564,7 +577,7 @@ bf_beamform_i8_kernel(const bf_bacc_args a)
             for (uint32_t q = 0; q < 4; q++)
                 if ((q & (tpr - 1u)) == slot) {
 #pragma unroll
-                    for (int d = 0; d < 3; d++) wx[(q * 6u + d) * 64u] = (uint32_t)wre[0][d][q], wx[(q * 6u + 3u + d) * 64u] = (uint32_t)wim[0][d][q];
+                    for (int d = 0; d < 3; d++) wx[(q * 6u + d) * 64u] = (uint32_t)wre[d][q], wx[(q * 6u + 3u + d) * 64u] = (uint32_t)wim[d][q];
                 }
         }
         __syncthreads(); // hipcc drains the LDS-DMA (vmcnt(0)) in front of it
@@ -574,11 +587,11 @@ bf_beamform_i8_kernel(const bf_bacc_args a)
             for (uint32_t q = 0; q < 4; q++)
                 if ((q & (tpr - 1u)) != slot) {
 #pragma unroll
-                    for (int d = 0; d < 3; d++) wre[0][d][q] = (int)wx[(q * 6u + d) * 64u], wim[0][d][q] = (int)wx[(q * 6u + 3u + d) * 64u];
+                    for (int d = 0; d < 3; d++) wre[d][q] = (int)wx[(q * 6u + d) * 64u], wim[d][q] = (int)wx[(q * 6u + 3u + d) * 64u];
                 }
         }
-    } else {
-        fetch(cur[1], NCH == 1 ? 2 : 0, NCH == 1 ? 0 : 1);
+    } else if (has_chunk) {
+        fetch(cur[1], 2);
     }
     if (bw + 16u <= a.B)
         run(std::true_type{});
@@ -604,7 +617,8 @@ hipError_t bf_launch_beamform_acc(const bf_bacc_args &a_in, hipStream_t stream)
     const bool chain = a.fp32_chain != 0u;
     // beam tiles per workgroup: as many as the beams need; the fp32 form keeps its coefficient planes in LDS and
     // takes as many as still admit 6 workgroups per CU (26 KiB each), one tile whatever it takes beyond
-    int nbt = a.B > 32u ? 4 : (a.B > 16u ? 2 : 1);
+    const bool split = !chain && a.A > 64u; // the int8 form's K-split: one beam tile per workgroup, a 64-antenna chunk per wave
+    int nbt = split ? 1 : (a.B > 32u ? 4 : (a.B > 16u ? 2 : 1));
     while (chain && nbt > 1 && bacc_lds_bytes(nbt, a.A) > 26u * 1024u) nbt >>= 1;
     const size_t lds = chain ? bacc_lds_bytes(nbt, a.A) : 0u;
     a.nbt_log2 = nbt == 4 ? 2u : (nbt == 2 ? 1u : 0u);
@@ -612,9 +626,9 @@ hipError_t bf_launch_beamform_acc(const bf_bacc_args &a_in, hipStream_t stream)
     // 16-sample blocks per workgroup: whole rounds of 4 / nbt blocks, at most max_rounds (the coefficients are
     // generated once per workgroup; but a launch of only a few thousand long-lived workgroups ends with most of the
     // chip idle behind the last ones), fewer while that leaves the chip under 4096 workgroups
-    const uint32_t tpr = 4u / (uint32_t)nbt;
+    const uint32_t tpr = split ? 1u : 4u / (uint32_t)nbt; // (K-split: every wave takes every block)
     const bool staged_form = !chain && a.A <= 64u && !a.unstaged; // at most 16 blocks (32 KiB of LDS) per workgroup
-    const uint32_t max_rounds = a.max_rounds ? a.max_rounds : (chain ? 16u : (staged_form ? 16u / tpr : 32u));
+    const uint32_t max_rounds = a.max_rounds ? a.max_rounds : (chain ? 16u : (staged_form || split ? 16u / tpr : 32u));
     uint32_t tiles = (a.nT16 + tpr - 1u) / tpr * tpr;
     if (tiles > max_rounds * tpr) { // several workgroups per (channel, beam group): equal shares (17 blocks are 9 + 8, not 16 + 1)
         const uint32_t parts = (a.nT16 + max_rounds * tpr - 1u) / (max_rounds * tpr);
@@ -636,34 +650,29 @@ hipError_t bf_launch_beamform_acc(const bf_bacc_args &a_in, hipStream_t stream)
             hipLaunchKernelGGL(bf_beamform_acc_kernel<2>, grid, block, lds, stream, a);
         else
             hipLaunchKernelGGL(bf_beamform_acc_kernel<1>, grid, block, lds, stream, a);
-    } else {
-        const uint32_t nch = a.A <= 64u ? 1u : (a.A <= 128u ? 2u : 4u);
-        const bool full = a.A == 64u * nch;
-#define DCS_I8(N)                                                                                   \
-    if (full)                                                                                       \
-        hipLaunchKernelGGL((bf_beamform_i8_kernel<N, true, false>), grid, block, 0, stream, a);   \
-    else                                                                                            \
-        hipLaunchKernelGGL((bf_beamform_i8_kernel<N, false, false>), grid, block, 0, stream, a)
-        if (nch == 1 && !a.unstaged) {
-            size_t stage_bytes = ((size_t)a.tiles_per_wg * a.A * 32u + 1023u) / 1024u * 1024u;
-            if (nbt < 4 && !a.no_share) { // waves that own the same tile share the making of its coefficients
-                a.share_off = (uint32_t)stage_bytes;
-                stage_bytes += (size_t)nbt * 4u * 6u * 64u * sizeof(uint32_t);
-            }
-            if (a.wg_per_cu >= 1u && a.wg_per_cu <= 5u && stage_bytes < 160u * 1024u / a.wg_per_cu) // residency cap: unused LDS
-                stage_bytes = (160u * 1024u / a.wg_per_cu) & ~1023u;
-            if (full)
-                hipLaunchKernelGGL((bf_beamform_i8_kernel<1, true, true>), grid, block, stage_bytes, stream, a);
-            else
-                hipLaunchKernelGGL((bf_beamform_i8_kernel<1, false, true>), grid, block, stage_bytes, stream, a);
-        } else if (nch == 1) {
-            DCS_I8(1);
-        } else if (nch == 2) {
-            DCS_I8(2);
-        } else {
-            DCS_I8(4);
+    } else if (a.A <= 64u && !a.unstaged) {
+        size_t stage_bytes = ((size_t)a.tiles_per_wg * a.A * 32u + 1023u) / 1024u * 1024u;
+        if (nbt < 4 && !a.no_share) { // waves that own the same tile share the making of its coefficients
+            a.share_off = (uint32_t)stage_bytes;
+            stage_bytes += (size_t)nbt * 4u * 6u * 64u * sizeof(uint32_t);
         }
-#undef DCS_I8
+        if (a.wg_per_cu >= 1u && a.wg_per_cu <= 5u && stage_bytes < 160u * 1024u / a.wg_per_cu) // residency cap: unused LDS
+            stage_bytes = (160u * 1024u / a.wg_per_cu) & ~1023u;
+        if (a.A == 64u)
+            hipLaunchKernelGGL((bf_beamform_i8_kernel<kStaged, true>), grid, block, stage_bytes, stream, a);
+        else
+            hipLaunchKernelGGL((bf_beamform_i8_kernel<kStaged, false>), grid, block, stage_bytes, stream, a);
+    } else if (a.A <= 64u) {
+        if (a.A == 64u)
+            hipLaunchKernelGGL((bf_beamform_i8_kernel<kDirect, true>), grid, block, 0, stream, a);
+        else
+            hipLaunchKernelGGL((bf_beamform_i8_kernel<kDirect, false>), grid, block, 0, stream, a);
+    } else { // 2 pairs x 4 registers x 4 chunks x 64 lanes x 16 bytes of partial sums
+        const size_t part_bytes = 2u * 4u * 4u * 64u * 16u;
+        if (a.A % 64u == 0u)
+            hipLaunchKernelGGL((bf_beamform_i8_kernel<kSplit, true>), grid, block, part_bytes, stream, a);
+        else
+            hipLaunchKernelGGL((bf_beamform_i8_kernel<kSplit, false>), grid, block, part_bytes, stream, a);
     }
     return hipGetLastError();
 }
