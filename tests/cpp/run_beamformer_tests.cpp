@@ -144,7 +144,9 @@ struct CoeffTest { // BeamformerCoeffTest for the three coefficient kernels, b32
 
 // BeamformerCoeffTest, COMBINED_COEFF_GEN_AND_BEAMFORMER_SINGLE_CHANNEL branch
 // (BeamformerCoefficientTest.cu:46-50,82-87,198-204,259-262,272-275,363-414).
-static int run_combined(float tol, float *kernel_ms_out, float *max_diff_out)
+// accumulated: the coefficients of ONE time (index 1) held for all samples -- ACCUMULATIONS_BEFORE_NEW_COEFFS,
+// BeamformerParameters.h:17 -- through dcs_bf_beamform_accumulated (the int8 matrix pipe); otherwise the per-sample kernel
+static int run_combined(float tol, float *kernel_ms_out, float *max_diff_out, bool accumulated = false)
 {
     dcs_bf_params p;
     DCS_ERRCHK(dcs_bf_default_params(&p));
@@ -171,7 +173,10 @@ static int run_combined(float tol, float *kernel_ms_out, float *max_diff_out)
     DCS_ERRCHK(dcs_event_create(&e0));
     DCS_ERRCHK(dcs_event_create(&e1));
     DCS_ERRCHK(dcs_event_record(e0, nullptr));
-    DCS_ERRCHK(dcs_bf_generate_and_beamform(ctx, 0, (uint32_t)nt, (const int8_t *)dAnt, antBytes, (float *)dBeams, beamBytes, nullptr));
+    if (accumulated)
+        DCS_ERRCHK(dcs_bf_beamform_accumulated(ctx, 1, (uint32_t)nt, (const int8_t *)dAnt, antBytes, (float *)dBeams, beamBytes, nullptr))
+    else
+        DCS_ERRCHK(dcs_bf_generate_and_beamform(ctx, 0, (uint32_t)nt, (const int8_t *)dAnt, antBytes, (float *)dBeams, beamBytes, nullptr));
     DCS_ERRCHK(dcs_event_record(e1, nullptr));
     DCS_ERRCHK(dcs_event_synchronize(e1));
     DCS_ERRCHK(dcs_event_elapsed_ms(e0, e1, kernel_ms_out));
@@ -179,7 +184,13 @@ static int run_combined(float tol, float *kernel_ms_out, float *max_diff_out)
     DCS_ERRCHK(dcs_stream_synchronize(nullptr));
     dcs_oracle_params op = {p.nr_channels, p.nr_stations, p.nr_beams, p.sampling_period, p.fft_size};
     std::vector<float> expect(beamBytes / sizeof(float));
-    dcs_oracle_beamform(&op, (const dcs_oracle_delay_vals *)hDelays, nt, hAnt, expect.data());   // verify_output :363-414
+    if (accumulated) {
+        float dt1 = 0;
+        DCS_ERRCHK(dcs_bf_delta_times(&p, 1, 1, &dt1));
+        dcs_oracle_beamform_accumulated(&op, (const dcs_oracle_delay_vals *)hDelays, dt1, nt, hAnt, expect.data());
+    } else {
+        dcs_oracle_beamform(&op, (const dcs_oracle_delay_vals *)hDelays, nt, hAnt, expect.data());   // verify_output :363-414
+    }
     float mx = 0;
     int result = 1;
     for (size_t i = 0; i < expect.size(); i++) {
@@ -224,6 +235,12 @@ int main()
             return 1;
         }
         std::printf("%-50s kernel %.3f ms, max |beam - CPU verifier| %g (tolerance 0.1)\n", "Combined Steering Coeffs+Beamforming", ms, mx);
+        if (run_combined(1e-1f, &ms, &mx, true) != 1 || !(mx <= 2e-5f * 64)) {
+            std::printf("Test failed, output data not generated correctly\n");
+            return 1;
+        }
+        std::printf("%-50s kernel %.3f ms, max |beam - CPU verifier| %g (tolerance 0.1; held to 2e-5 * antennas)\n",
+                    "Beamforming, coefficients held for 256 samples", ms, mx);
     }
     std::printf("%-50s%-20s%-20s%-10s\n", "Kernel Name", "GPU Utilisation", "GPU Utilisation", "max ULP (b16: half-ULP)");
     for (const Case &c : cases) {
