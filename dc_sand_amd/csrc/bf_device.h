@@ -37,7 +37,7 @@ __device__ __forceinline__ void coeff_fast(const float fRate, const float fPhase
                                            const float D, const float y, float &re, float &im)
 {
     const float rot = dcs_rotation<DIV3>(fRate, fPhase0, fChan, D, y);
-#ifdef DCS_USE_OCML_SINCOS // A/B build only (tools/sincos_ab.py): __ocml_sincos_f32
+#ifdef DCS_USE_OCML_SINCOS // A/B build only (tools/measure.py sincos with DCS_HIPCC_EXTRA=-DDCS_USE_OCML_SINCOS): __ocml_sincos_f32
     sincosf(rot, &im, &re);
 #else
     dcs_sincos_fast<LOWDEG>(rot, &im, &re);

@@ -266,7 +266,7 @@ __global__ void __launch_bounds__(kBlock) bf_tiled_kernel(const std::conditional
 // ---------------------------------------------------------------------------
 // Row-streaming generator ("rows" form): the form the HBM system likes best.
 //
-// tools/explore_patterns.py (profiles/r01_store_patterns.md) shows that the
+// tools/measure.py stores --kind pattern (profiles/r01_store_patterns.md) shows that the
 // write rate MI355X sustains depends on how long a wave keeps storing: waves
 // that issue 1 / 2 / 4 stores and retire, dispatched in address order, reach
 // 7.1 / 6.9 / 6.6 TB/s; waves that walk hundreds of rows reach 5.5 TB/s.  So

@@ -30,7 +30,7 @@ int dcs_probe_sincos(int which, const float *d_x, size_t n, float *d_sin, float 
  * measured HBM-write ceiling the roofline fraction is read against. */
 int dcs_probe_fill(void *d_out, size_t bytes, int nontemporal, void *stream);
 /* Store-only kernel over a `rows` x `cols_kib` KiB matrix: each workgroup owns a
- * rectangle of rb rows x qb KiB (tools/explore_patterns.py maps out which write
+ * rectangle of rb rows x qb KiB (tools/measure.py stores --kind pattern maps out which write
  * patterns the HBM system sustains; profiles/r01_store_patterns.md).  xcd_remap is a
  * bit set: 1 = workgroups sharing blockIdx % 8 take consecutive rectangles, 2 = a wave
  * takes consecutive 1-KiB chunks instead of every n-th, bits 4-6 = rotate the rectangle
