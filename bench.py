@@ -239,7 +239,7 @@ def extras(gen, bp, out, out_bytes, sh, device, sustain_seconds: float) -> dict:
     # -- the same beamformer with the coefficients of ONE time reused for 256 samples (ACCUMULATIONS_BEFORE_NEW_COEFFS,
     #    BeamformerParameters.h:17): exact fixed-point contraction on the int8 matrix pipe; roofline = HBM
     res["beamform_accumulated"] = []
-    for (A, B, C, nt) in ((64, 16, 4096, 256), (64, 256, 1024, 256)):
+    for (A, B, C, nt) in ((64, 16, 32768, 256), (64, 256, 4096, 256)):
         fp = BeamformerParameters(NR_CHANNELS=C, NR_STATIONS=A, NR_BEAMS=B, NR_SAMPLES_PER_CHANNEL=nt)
         g = SteeringCoefficientGenerator(fp)
         g.upload_delays(simulate_input(fp), stream=sh)
