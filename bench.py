@@ -114,7 +114,7 @@ def cpu_baseline(bp, table, seconds: float) -> dict:
     from dc_sand_amd.generator import simulate_input
 
     A, B, nt = 64, 16, 256
-    C = max(1, int(min(1024, 550 * seconds / 12.0)))  # ~1 s at the default --cpu-seconds
+    C = max(1, int(min(8192, 6000 * seconds / 12.0)))  # ~1 s at the default --cpu-seconds
     fp = BeamformerParameters(NR_CHANNELS=C, NR_STATIONS=A, NR_BEAMS=B, NR_SAMPLES_PER_CHANNEL=nt)
     fop = orc.params_from(fp)
     ant = orc.simulate_antenna_data(fop, nt)
@@ -122,7 +122,7 @@ def cpu_baseline(bp, table, seconds: float) -> dict:
     with orc.trig_reading(orc.FLOAT_LIBM):
         orc.beamform_accumulated(fop, simulate_input(fp), np.float32(0.0008192), nt, ant)
     sb = _time.perf_counter() - t0
-    out["beamform_accumulated"] = {"value": A * B * C * nt / sb / 1e9, "unit": "T coefficient-products/s", "cores": 1, "kind": "port",
+    out["beamform_accumulated"] = {"value": A * B * C * nt / sb / 1e12, "unit": "T coefficient-products/s", "cores": 1, "kind": "port",
                                    "sample": f"{A}ant x {B}beam x {C}chan x {nt}samples in {sb:.2f} s, 1 thread"}
     return out
 

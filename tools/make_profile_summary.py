@@ -8,7 +8,7 @@ import sys
 
 R = "/root/repo/"
 tag, bench_json, rnd = sys.argv[1], sys.argv[2], sys.argv[3]  # e.g. prof5 bench5.json r01
-f = glob.glob(R + f"gpurun_out/{tag}_kt/runc/*_kernel_trace.csv")[0]
+f = glob.glob(R + f"gpurun_out/{tag}_kt/**/*kernel_trace.csv", recursive=True)[0]
 import re
 
 # production symbol of the fp32 generator: bf_tiled_kernel<false, TPB, NT, ALIGNED, NOMATH=false, TAG=0, INL, TERMS, HALF>;
@@ -25,7 +25,7 @@ bench_rows = rows[-60:]  # 10 warm-up + 50 timed
 d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in bench_rows]
 timed = d[10:]
 vg = bench_rows[-1]
-shutil.copy(glob.glob(R + f"gpurun_out/{tag}_kt/runc/*_kernel_stats.csv")[0], R + f"profiles/{rnd}_bench_kernel_stats.csv")
+shutil.copy(glob.glob(R + f"gpurun_out/{tag}_kt/**/*kernel_stats.csv", recursive=True)[0], R + f"profiles/{rnd}_bench_kernel_stats.csv")
 shutil.copy(R + "gpurun_out/" + bench_json, R + f"profiles/{rnd}_bench_n1.json")
 prof = None
 for l in open(R + f"gpurun_out/{tag}_kt.log"):
@@ -35,7 +35,7 @@ for l in open(R + f"gpurun_out/{tag}_kt.log"):
 b = json.loads(open(R + "gpurun_out/" + bench_json).read())
 res = {}
 for d_, name in ((f"{tag}_pmc_w", "WRITE_SIZE"), (f"{tag}_pmc_f", "FETCH_SIZE")):
-    ff = glob.glob(R + f"gpurun_out/{d_}/runc/*_counter_collection.csv")[0]
+    ff = glob.glob(R + f"gpurun_out/{d_}/**/*counter_collection.csv", recursive=True)[0]
     v = [float(r["Counter_Value"]) for r in csv.DictReader(open(ff)) if is_prod(r["Kernel_Name"]) and r["Counter_Name"] == name]
     res[name] = (len(v), st.mean(v))
     shutil.copy(ff, R + f"profiles/{rnd}_pmc_{name.lower()}_counter_collection.csv")
@@ -66,16 +66,18 @@ cb = b.get("cpu_baseline", {})
 allms = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in rows]
 md = f"""# {rnd} — bench.py under rocprofv3 (MI355X, ROCm 7.2; final build of the round)
 
-Commands (from /tmp, `TMPDIR=/tmp`; program directly after `--`):
+Commands (`bash tools/profile_bench.sh`; the profiler from /tmp with `TMPDIR=/tmp`, program directly after `--`):
 
 ```
 python bench.py                                                          -> {rnd}_bench_n1.json
-rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --no-cpu-baseline
+rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --no-cpu-baseline --no-extras
                                                                          -> {rnd}_bench_kernel_stats.csv, {rnd}_bench_n1_under_rocprof.json
-rocprofv3 --pmc WRITE_SIZE --output-format csv -- python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline
-rocprofv3 --pmc FETCH_SIZE --output-format csv -- python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline
+rocprofv3 --pmc WRITE_SIZE --output-format csv -- python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-extras
+rocprofv3 --pmc FETCH_SIZE --output-format csv -- python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-extras
                                                                          -> {rnd}_pmc_*_counter_collection.csv, pmc_write_size.json
 ```
+(`--no-extras`: without the side measurements of `also_measured`, so that the last 60 dispatches of the production kernel are the
+10 warm-up + 50 timed steps.)
 
 Dominant kernel: `{vg['Kernel_Name'].split('(')[1] if False else vg['Kernel_Name'][:100]}` (fp32, 1 tile per workgroup, nontemporal stores,
 terms-table variant: its pre-pass `bf_terms_kernel` is the other kernel of every step, ~3 us; the `<..., 1, ...>` rows of the stats file
