@@ -102,5 +102,12 @@ still 3-10 % slower than steady state and fall in the W = 10 warm-up steps.  The
 trace of the same launches and the `--stats` average agree within 1 % (the event span also holds the 5-us slice gather and the gaps between launches, which grow a little under the profiler).  HBM traffic equals the algorithmic bytes: every store is a whole-line write,
 nothing is re-read.  Box-to-box spread seen this round: 915-930 Gcoeff/s (five boxes).
 """
+# (a section appended by hand below a "## A minute of back-to-back steps" heading survives regeneration)
+try:
+    old = open(R + f"profiles/{rnd}_bench_profile.md").read()
+    if "\n## A minute" in old:
+        md += old[old.index("\n## A minute"):]
+except FileNotFoundError:
+    pass
 open(R + f"profiles/{rnd}_bench_profile.md", "w").write(md)
 print(md[md.index("| quantity"):])
