@@ -129,14 +129,17 @@ struct bf_bacc_args {
     float *beams;          // [C][nT16][B][16][2]
     uint32_t A, B, C, nT16;
     uint32_t fp32_chain;   // 0: exact fixed-point contraction on the int8 matrix pipe; 1: fp32 fma chain (v_mfma_f32_16x16x4_f32)
-    uint32_t max_rounds;   // 0 = the launcher's choice
     uint32_t share_off;    // staged int8 form: LDS offset of the coefficient exchange (filled by the launcher; 0 = none)
+    // A/B switches of the measurements in profiles/r02_fused.md; all 0 in the product (bf_capi.hip sets them from the
+    // environment in the probes build only):
+    uint32_t max_rounds;   // cap on the rounds of sample blocks per workgroup (0 = the launcher's choice)
     uint32_t no_share;     // staged int8 form: every wave makes all its coefficients
     uint32_t plain_stores; // int8 form: ordinary instead of nontemporal stores
     uint32_t wg_per_cu;    // staged int8 form: at most this many workgroups resident per CU (0 = as many as fit)
     uint32_t unstaged;     // int8 form, <= 64 antennas: operands straight from global memory instead of through LDS
 #ifdef DCS_PROBES
-    uint32_t probe;        // probes build only: 1 = stores only, 2 = loads and stores without arithmetic
+    uint32_t probe;        // 1 = stores only, 2 = loads and stores without arithmetic, 3 = stores without coefficients either,
+                           // 4 = as 3 with one contiguous KiB per store instruction
 #endif
     uint32_t tiles_per_wg, n_bgroups, n_tgroups, nbt_log2; // filled by the launcher
     dcs_bf_consts k;
