@@ -59,6 +59,8 @@ def parse():
                          "untimed set-up (its trial launches run under separate kernel symbols, template TAG = 1, so a "
                          "rocprofv3 --stats of this command still averages only the production launches)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline sample time")
+    ap.add_argument("--output-alloc", default="torch", choices=["torch", "hip"],
+                    help="who allocates the output tensor: torch's caching allocator (default) or hipMalloc through dc_sand_amd.device (measured: no difference)")
     ap.add_argument("--sustain-seconds", type=float, default=5.0, help="length of the sustained-rate side measurement (N = 1)")
     # rehearsal of the N > 1 control flow on a box with fewer GPUs than ranks (never a result):
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="nccl = RCCL over xGMI (the product path)")
@@ -327,7 +329,17 @@ def main():
     beam_off = rank * args.beams_per_gpu
     gen = SteeringCoefficientGenerator(bp)
     out_bytes = gen.output_bytes(1, 1)
-    out = torch.empty(out_bytes, dtype=torch.uint8, device="cuda")
+    if args.output_alloc == "torch":
+        out = torch.empty(out_bytes, dtype=torch.uint8, device="cuda")
+    else:  # plain hipMalloc through the library's device helpers (the pycuda-shaped host of the reference allocates so)
+        class _HipBuffer:
+            def __init__(self, nbytes):
+                self._mem = device.mem_alloc(nbytes)
+
+            def data_ptr(self):
+                return int(self._mem)
+
+        out = _HipBuffer(out_bytes)
     # one explicit non-blocking stream for everything (not the legacy null stream, which synchronises
     # implicitly with every blocking stream a library may have created); it is also torch's current
     # stream, so the process group orders its collectives against it
