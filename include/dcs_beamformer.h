@@ -235,7 +235,9 @@ int dcs_bf_generate_and_beamform_dt(dcs_bf_context *ctx, const float *dt, uint32
  * 8355711 in fp32 at the end.  Against the exact sum of the fp32 coefficients times the samples the result is
  * within 9e-8 * sum_a |sample_a| + 1.5 ulp -- closer than the verifier's own fp32 loop (BCT.cu:363-414 with the
  * coefficient held: sum += coeff * sample, whose partial sums round at every antenna) -- and within
- * 2e-5 * nr_stations of that loop, against the reference's tolerance of 1e-1 (runBeamformerTests.cpp:15).
+ * 4e-5 * nr_stations of that loop in the worst case (every sample at full scale and every error aligned: 1 ulp of
+ * the coefficient + the quantisation + the roundings of either side, 3e-7 * 128 per antenna; typically 10 x less),
+ * against the reference's tolerance of 1e-1 (runBeamformerTests.cpp:15).
  * dcs_bf_tuning.math_mode bit 3 selects the other form: v_mfma_f32_16x16x4_f32, exact fp32 products
  * accumulated as an fma chain in antenna order (differs from the verifier's loop by the chain's single
  * roundings only; same bound; 1/32 of the int8 pipe's rate).  nr_stations <= 256; d_antenna 16-byte aligned.

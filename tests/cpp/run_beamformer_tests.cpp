@@ -235,11 +235,11 @@ int main()
             return 1;
         }
         std::printf("%-50s kernel %.3f ms, max |beam - CPU verifier| %g (tolerance 0.1)\n", "Combined Steering Coeffs+Beamforming", ms, mx);
-        if (run_combined(1e-1f, &ms, &mx, true) != 1 || !(mx <= 2e-5f * 64)) {
+        if (run_combined(1e-1f, &ms, &mx, true) != 1 || !(mx <= 4e-5f * 64)) {
             std::printf("Test failed, output data not generated correctly\n");
             return 1;
         }
-        std::printf("%-50s kernel %.3f ms, max |beam - CPU verifier| %g (tolerance 0.1; held to 2e-5 * antennas)\n",
+        std::printf("%-50s kernel %.3f ms, max |beam - CPU verifier| %g (tolerance 0.1; held to 4e-5 * antennas)\n",
                     "Beamforming, coefficients held for 256 samples", ms, mx);
     }
     std::printf("%-50s%-20s%-20s%-10s\n", "Kernel Name", "GPU Utilisation", "GPU Utilisation", "max ULP (b16: half-ULP)");

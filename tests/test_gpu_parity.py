@@ -1249,7 +1249,8 @@ def test_beamform_accumulated_on_the_matrix_cores(gpu, oracle, A, B, C, nt, math
     (BeamformerCoefficientTest.cu:363-414).  Both forms: the default exact fixed-point contraction on the int8 pipe
     (24-bit coefficients as three signed digits; sums exact) and (math_mode 8) the fp32 fma chain on
     v_mfma_f32_16x16x4_f32.  The verifier multiplies and adds with separate roundings, and each coefficient is within
-    1 ULP: |difference| <= 2e-5 * A (the bound the per-sample fused kernel is held to); the reference's own tolerance is
+    1 ULP: |difference| <= 4e-5 * A (1 ulp of the coefficient + quantisation + the roundings of either side <= 3e-7 per unit of
+    sample, samples <= 128: reached at A = 1, ten times less at 64 antennas); the reference's own tolerance is
     1e-1 (runBeamformerTests.cpp:15).  The fixed-point form is also held to its own, much tighter, bound against the
     sum in exact (fp64) arithmetic of the oracle's fp32 coefficients: 2.5e-7 * sum_a |sample_a| + 2e-7 * |sum|.
     Shapes cover every beam-tile count (1, 2, 4 per workgroup: coefficients shared by 4, 2, 1 waves), ragged antennas /
@@ -1282,7 +1283,7 @@ def test_beamform_accumulated_on_the_matrix_cores(gpu, oracle, A, B, C, nt, math
     got = host[:exp.nbytes].view(np.float32).reshape(exp.shape)
     assert np.all(np.isfinite(got))
     diff = np.abs(got - exp)
-    assert diff.max() <= 2e-5 * A + 1e-6, diff.max()
+    assert diff.max() <= 4e-5 * A + 1e-6, diff.max()
     assert oracle.compare(got, exp, 1e-1) == -1
     if math_mode == 0:
         # exact-arithmetic sum of the oracle's coefficients (table [b*A + a] -> the generator's [a*B + b])
@@ -1297,6 +1298,63 @@ def test_beamform_accumulated_on_the_matrix_cores(gpu, oracle, A, B, C, nt, math
     gpu.memcpy_dtoh(got2, d_beams)
     assert np.array_equal(got2.view(np.uint32), got.view(np.uint32))
     g.close()
+
+
+def test_beamform_accumulated_seeded_fuzz(gpu, oracle):
+    """60 seeded random cases of the coefficient-reuse beamformer: antennas 1..256 (every form: staged, K-split with
+    2-4 chunks, whole and partial), beams 1..90 (1, 2, 4 tiles per workgroup, partial tiles), channels, 1..40 sample
+    blocks (odd counts, several workgroups per channel), either arithmetic form, time by index or by value -- each
+    within 4e-5 * A of the verifier's loop with the coefficient held, the fixed-point form also within its own bound of
+    the exact sum, nothing written outside the tensor."""
+    from dc_sand_amd import BeamformerParameters
+    from dc_sand_amd.generator import SteeringCoefficientGenerator, delta_times
+
+    rng = np.random.default_rng(20261005)
+    for case in range(60):
+        A = int(rng.choice([1, 3, 17, 63, 64, 65, 100, 128, 129, 191, 192, 200, 255, 256])) if case % 2 else int(rng.integers(1, 257))
+        B = int(rng.integers(1, 91))
+        C = int(rng.integers(1, 5))
+        nblk = int(rng.integers(1, 41))
+        if A * B * C * nblk > 600000:  # keep the oracle's work small
+            nblk = max(1, 600000 // (A * B * C))
+        nt = 16 * nblk
+        math_mode = 8 if case % 5 == 0 else 0
+        bp = BeamformerParameters(NR_CHANNELS=C, NR_STATIONS=A, NR_BEAMS=B, NR_SAMPLES_PER_CHANNEL=nt)
+        op = oracle.params_from(bp)
+        table = rand_table(bp.n_pairs, seed=3000 + case)  # indexed [b*A + a]
+        ant = rng.integers(-128, 128, size=(C, nblk, A, 16, 2), dtype=np.int8)
+        by_value = bool(rng.integers(0, 2))
+        t_coeff = int(rng.integers(0, 2000))
+        dt = np.float32(rng.uniform(0.0, 1.5)) if by_value else delta_times(bp, t_coeff, 1)[0]
+        exp = oracle.beamform_accumulated(op, table, dt, nt, ant)
+        g = SteeringCoefficientGenerator(bp)
+        g.upload_delays(table)
+        if math_mode:
+            g.set_tuning(math_mode=math_mode)
+        d_ant = gpu.mem_alloc(ant.nbytes)
+        gpu.memcpy_htod(d_ant, ant)
+        d_beams = gpu.mem_alloc(exp.nbytes + 64)
+        gpu.memset(d_beams, 0xFF, exp.nbytes + 64)
+        if by_value:
+            g.beamform_accumulated(d_ant, ant.nbytes, d_beams, exp.nbytes, nt, dt_coeff=float(dt))
+        else:
+            g.beamform_accumulated(d_ant, ant.nbytes, d_beams, exp.nbytes, nt, t_coeff=t_coeff)
+        host = np.empty(exp.nbytes + 64, dtype=np.uint8)
+        gpu.memcpy_dtoh(host, d_beams)
+        tag = (case, A, B, C, nt, math_mode, by_value)
+        assert np.all(host[exp.nbytes:] == 0xFF), tag
+        got = host[:exp.nbytes].view(np.float32).reshape(exp.shape)
+        assert np.all(np.isfinite(got)), tag
+        assert np.abs(got - exp).max() <= 4e-5 * A + 1e-6, (tag, float(np.abs(got - exp).max()))
+        if math_mode == 0:
+            coef = oracle.generate_dt(op, np.ascontiguousarray(table.reshape(B, A).T).ravel(), dt)[0].astype(np.float64)
+            x = ant.astype(np.float64)
+            exact = np.einsum("cabk,ctaik->ctbik", coef, x)
+            mag = np.abs(x).sum(axis=2)[:, :, None, :, :]
+            assert np.all(np.abs(got - exact) <= 2.5e-7 * mag + 2e-7 * np.abs(exact) + 1e-30), tag
+        g.close()
+        d_ant.free()
+        d_beams.free()
 
 
 def test_beamform_accumulated_slow_class_and_limits(gpu, oracle):
