@@ -565,6 +565,57 @@ def test_fused_coefficient_generation_and_beamforming(gpu, oracle, A, B, C, nt, 
     g.close()
 
 
+def test_fused_seeded_fuzz(gpu, oracle):
+    """40 seeded random cases of the per-sample fused kernel: antennas 1..300 (several 128-antenna LDS chunks), beams
+    1..70 (partial 16-beam groups), channels (odd counts: the two-channels-per-pass loop's tail), 1..6 sample blocks,
+    a time offset, times by index or by value -- each within 2e-5 * A of the verifier (same summation order: the only
+    difference is each coefficient's <= 1 ULP), nothing written outside the tensor."""
+    from dc_sand_amd import BeamformerParameters
+    from dc_sand_amd.generator import SteeringCoefficientGenerator, delta_times
+
+    rng = np.random.default_rng(20261006)
+    for case in range(40):
+        A = int(rng.choice([1, 2, 63, 64, 65, 127, 128, 129, 256, 257, 300])) if case % 2 else int(rng.integers(1, 200))
+        B = int(rng.integers(1, 71))
+        C = int(rng.integers(1, 8))
+        nblk = int(rng.integers(1, 7))
+        while A * B * C * nblk * 16 > 400000 and nblk > 1:
+            nblk -= 1
+        while A * B * C * nblk * 16 > 400000 and C > 1:
+            C -= 1
+        nt = 16 * nblk
+        bp = BeamformerParameters(NR_CHANNELS=C, NR_STATIONS=A, NR_BEAMS=B, NR_SAMPLES_PER_CHANNEL=nt)
+        op = oracle.params_from(bp)
+        table = rand_table(bp.n_pairs, seed=5000 + case)
+        ant = rng.integers(-128, 128, size=(C, nblk, A, 16, 2), dtype=np.int8)
+        by_value = bool(rng.integers(0, 2))
+        if by_value:
+            dts = rng.uniform(0.0, 0.3, size=nt).astype(np.float32)
+            exp = oracle.beamform_dt(op, table, dts, ant)
+        else:
+            exp = oracle.beamform(op, table, nt, ant)
+        g = SteeringCoefficientGenerator(bp)
+        g.upload_delays(table)
+        d_ant = gpu.mem_alloc(ant.nbytes)
+        gpu.memcpy_htod(d_ant, ant)
+        d_beams = gpu.mem_alloc(exp.nbytes + 64)
+        gpu.memset(d_beams, 0xFF, exp.nbytes + 64)
+        if by_value:
+            g.generate_and_beamform_dt(d_ant, ant.nbytes, d_beams, exp.nbytes, dts)
+        else:
+            g.generate_and_beamform(d_ant, ant.nbytes, d_beams, exp.nbytes, t0=0, nt=nt)
+        host = np.empty(exp.nbytes + 64, dtype=np.uint8)
+        gpu.memcpy_dtoh(host, d_beams)
+        tag = (case, A, B, C, nt, by_value)
+        assert np.all(host[exp.nbytes:] == 0xFF), tag
+        got = host[:exp.nbytes].view(np.float32).reshape(exp.shape)
+        assert np.all(np.isfinite(got)), tag
+        assert np.abs(got - exp).max() <= 2e-5 * A + 1e-6, (tag, float(np.abs(got - exp).max()))
+        g.close()
+        d_ant.free()
+        d_beams.free()
+
+
 def test_fused_harness_and_slow_path(gpu, oracle):
     from dc_sand_amd import BeamformerParameters
     from dc_sand_amd.beamformer_coeff_test import BeamformerCoeffTest, SteeringCoefficientBitWidth as BW, SteeringCoefficientKernel as K
