@@ -1124,6 +1124,54 @@ def test_generate_dt_more_steps_than_ride_in_the_kernel_arguments(gpu, oracle, f
     g.close()
 
 
+def test_generate_dt_seeded_fuzz_over_the_whole_time_and_rate_range(gpu, oracle):
+    """50 seeded random cases of dcs_bf_generate_dt: fDeltaTime from 1e-7 s to 1e4 s of either sign (and 0), delay
+    tables whose rates span nine decades on top of the usual ones -- so that waves land in every class (low-degree,
+    full, slow: |fRotation| from 1e-3 to far beyond 32000) -- every launch shape, several time steps at once, fp32 within
+    1 ULP of the verifier (the tolerance rule applies only where |fRotation| is small enough for 1e-4 to mean anything)
+    and fp16 the RN-even image of the fp32 run."""
+    from dc_sand_amd import BeamformerParameters
+    from dc_sand_amd.generator import SteeringCoefficientGenerator
+
+    rng = np.random.default_rng(20261007)
+    for case in range(50):
+        A, B, C = int(rng.integers(1, 7)), int(rng.integers(1, 40)), int(rng.integers(1, 50))
+        bp = BeamformerParameters(NR_CHANNELS=C, NR_STATIONS=A, NR_BEAMS=B)
+        op = oracle.params_from(bp)
+        table = rand_table(bp.n_pairs, seed=7000 + case)
+        if case % 3 == 0:  # a few pairs with rates far outside the usual range
+            k = rng.integers(0, bp.n_pairs, size=max(1, bp.n_pairs // 5))
+            table["fDelayRate_sps"][k] = (10.0 ** rng.uniform(-12, -3, size=k.size)) * rng.choice([-1.0, 1.0], size=k.size)
+            table["fPhaseRate_radps"][k] = (10.0 ** rng.uniform(-9, 2, size=k.size)) * rng.choice([-1.0, 1.0], size=k.size)
+        nt = int(rng.integers(1, 6))
+        dts = ((10.0 ** rng.uniform(-7, 4, size=nt)) * rng.choice([-1.0, 1.0], size=nt)).astype(np.float32)
+        if case % 7 == 0:
+            dts[0] = 0.0
+        kernel = int(rng.integers(0, 3))
+        g = SteeringCoefficientGenerator(bp)
+        g.upload_delays(table)
+        nb = g.output_bytes(1, nt)
+        buf = gpu.mem_alloc(nb + 64)
+        gpu.memset(buf, 0xFF, nb + 64)
+        g.generate_dt(buf, nb, dts, kernel=kernel)
+        host = np.empty(nb + 64, dtype=np.uint8)
+        gpu.memcpy_dtoh(host, buf)
+        tag = (case, A, B, C, nt, kernel, dts.tolist())
+        assert np.all(host[nb:] == 0xFF), tag
+        got = host[:nb].view(np.float32).reshape(nt, C, A, B, 2)
+        exp = oracle.generate_dt(op, table, dts)
+        mx, n_over, first = oracle.max_ulp(got, exp, 1)
+        assert n_over == 0, (tag, mx, n_over, first)
+        if kernel != 0:
+            nb16 = g.output_bytes(0, nt)
+            g.generate_dt(buf, nb16, dts, kernel=kernel, bitwidth=0)
+            h16 = np.empty(got.shape, dtype=np.float16)
+            gpu.memcpy_dtoh(h16, buf)
+            assert np.array_equal(h16.view(np.uint16), got.astype(np.float16).view(np.uint16)), tag
+        g.close()
+        buf.free()
+
+
 @pytest.mark.parametrize("kernel", [0, 1, 2])
 def test_generate_at_timespec_pairs_across_a_seconds_boundary(gpu, oracle, kernel):
     """dcs_bf_generate_at: (current, reference) as the reference's kernels take them.  Times 200 us apart that cross a
