@@ -1124,6 +1124,39 @@ def test_generate_dt_more_steps_than_ride_in_the_kernel_arguments(gpu, oracle, f
     g.close()
 
 
+@pytest.mark.parametrize("kernel", [0, 1, 2])
+def test_non_finite_delay_values_give_the_verifiers_nans(gpu, oracle, kernel):
+    """Infinities and NaNs in the delay table (and a rate of 1e38): the coefficients of those pairs are NaN exactly where
+    the verifier's are (cos(inf) = NaN, inf * 0 = NaN at channel 0 ...), every other element is within 1 ULP, nothing
+    hangs.  The reference does not test this; the slow class (IEEE divide, fp64 sincos) is what these pairs fall into."""
+    from dc_sand_amd import BeamformerParameters
+    from dc_sand_amd.generator import SteeringCoefficientGenerator
+
+    bp = BeamformerParameters(NR_CHANNELS=6, NR_STATIONS=3, NR_BEAMS=7)
+    op = oracle.params_from(bp)
+    table = rand_table(bp.n_pairs, seed=5)
+    table["fDelayRate_sps"][2] = np.inf
+    table["fDelay_s"][5] = np.nan
+    table["fPhase_rad"][9] = -np.inf
+    table["fPhaseRate_radps"][13] = np.nan
+    table["fDelayRate_sps"][17] = 1e38
+    g = SteeringCoefficientGenerator(bp)
+    g.upload_delays(table)
+    dts = np.array([0.0, 0.37], dtype=np.float32)
+    nb = g.output_bytes(1, dts.size)
+    buf = gpu.mem_alloc(nb)
+    g.generate_dt(buf, nb, dts, kernel=kernel)
+    got = np.empty((dts.size, 6, 3, 7, 2), dtype=np.float32)
+    gpu.memcpy_dtoh(got, buf)
+    exp = oracle.generate_dt(op, table, dts)
+    assert np.isnan(exp).sum() > 50
+    assert np.array_equal(np.isnan(exp), np.isnan(got))
+    fin = ~np.isnan(exp)
+    mx, n_over, _ = oracle.max_ulp(np.where(fin, got, 0).astype(np.float32), np.where(fin, exp, 0).astype(np.float32), 1)
+    assert n_over == 0, mx
+    g.close()
+
+
 def test_generate_dt_seeded_fuzz_over_the_whole_time_and_rate_range(gpu, oracle):
     """50 seeded random cases of dcs_bf_generate_dt: fDeltaTime from 1e-7 s to 1e4 s of either sign (and 0), delay
     tables whose rates span nine decades on top of the usual ones -- so that waves land in every class (low-degree,
