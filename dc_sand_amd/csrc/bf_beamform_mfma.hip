@@ -286,6 +286,10 @@ bf_beamform_i8_kernel(const bf_bacc_args a)
     intx4 wre[3], wim[3];
 #pragma unroll
     for (int d = 0; d < 3; d++) wre[d] = wim[d] = intx4{0, 0, 0, 0};
+    // A coefficient that is not finite (an infinite or NaN delay value: the slow class) has no fixed-point digits; the
+    // verifier's sum for that beam and plane is NaN whatever the samples are (NaN * 0 = NaN), and so it is here: the lanes
+    // note it, the wave folds the notes into one bit per result row and plane, and the rows are stored as NaN.
+    bool bad_re = false, bad_im = false;
     auto make_coefficients = [&]() {
         // row i of the result tile is beam 4 (i & 3) + (i >> 2): the four lane groups of a store instruction then
         // hold four CONSECUTIVE beams (512 contiguous bytes per block) instead of every fourth
@@ -301,12 +305,16 @@ bf_beamform_i8_kernel(const bf_bacc_args a)
             out[0] = __builtin_amdgcn_perm(t3, t1, 0x05040100u); // bytes 2: d1
         };
         // antennas 64 kc + 4 (4 q + z) + lg, z = 0..3, from their terms: one register of each of the six operands
-        auto four = [&](auto gen, uint32_t q, const floatx2 (&k4)[4], uint32_t (&nr)[3], uint32_t (&ni)[3]) {
+        auto four = [&](auto gen, auto track, uint32_t q, const floatx2 (&k4)[4], uint32_t (&nr)[3], uint32_t (&ni)[3]) {
             uint32_t gr[4], gi[4];
 #pragma unroll
             for (uint32_t z = 0; z < 4; z++) {
                 float re, im;
                 gen(k4[z].x, k4[z].y, re, im);
+                if (decltype(track)::value) { // the slow class only: infinite or NaN delay values end here
+                    bad_re |= !(fabsf(re) <= 2.0f);
+                    bad_im |= !(fabsf(im) <= 2.0f);
+                }
                 gr[z] = fixed_word(re), gi[z] = fixed_word(im);
             }
             planes(gr, nr), planes(gi, ni);
@@ -331,7 +339,7 @@ bf_beamform_i8_kernel(const bf_bacc_args a)
                     if (shared_w && (q & (tpr - 1u)) != slot) continue; // a wave sharing its tile makes its own registers only
                     const floatx2 k4[4] = {kp[4 * q], kp[4 * q + 1], kp[4 * q + 2], kp[4 * q + 3]};
                     uint32_t nr[3], ni[3];
-                    four(gen, q, k4, nr, ni);
+                    four(gen, std::false_type{}, q, k4, nr, ni);
 #pragma unroll
                     for (int d = 0; d < 3; d++) wre[d][q] = (int)nr[d], wim[d][q] = (int)ni[d];
                 }
@@ -341,7 +349,7 @@ bf_beamform_i8_kernel(const bf_bacc_args a)
                 for (uint32_t q = 0; q < 4; q++) {
                     const floatx2 k4[4] = {kp[0], kp[1], kp[2], kp[3]};
                     uint32_t nr[3], ni[3];
-                    four(gen, q, k4, nr, ni);
+                    four(gen, std::true_type{}, q, k4, nr, ni);
 #pragma unroll
                     for (int d = 0; d < 3; d++) {
                         wre[d] = intx4{wre[d][1], wre[d][2], wre[d][3], (int)nr[d]};
@@ -445,6 +453,13 @@ bf_beamform_i8_kernel(const bf_bacc_args a)
         }
     };
     const float inv = 1.0f / kFixScale;
+    uint32_t nan_re = 0, nan_im = 0;     // wave-uniform: rows whose re / im plane is NaN (set once the coefficients are made)
+    const float fNaN = __builtin_nanf("");
+    // register r of this lane is result row 4 lg + r
+    auto poison = [&](int r, floatx4 &o) { // o = {re even, im even, re odd, im odd}
+        if ((nan_re >> (4u * lg + (uint32_t)r)) & 1u) o[0] = fNaN, o[2] = fNaN;
+        if ((nan_im >> (4u * lg + (uint32_t)r)) & 1u) o[1] = fNaN, o[3] = fNaN;
+    };
     const uint32_t bb = bw + lg;         // register r of this lane: beam bb + 4 r
     const uint32_t out_blk = a.B * 128u; // bytes per 16-sample block of one channel
     char *out8 = reinterpret_cast<char *>(a.beams);
@@ -464,7 +479,8 @@ bf_beamform_i8_kernel(const bf_bacc_args a)
     auto finish = [&](auto whole, uint32_t blk, const floatx4 (&f)[4]) {
 #pragma unroll
         for (int r = 0; r < 4; r++) { // beam bb + 4 r
-            const floatx4 o = {f[0][r] * inv, f[1][r] * inv, f[2][r] * inv, f[3][r] * inv};
+            floatx4 o = {f[0][r] * inv, f[1][r] * inv, f[2][r] * inv, f[3][r] * inv};
+            if (nan_re | nan_im) poison(r, o);
             if (decltype(whole)::value || bb + 4u * r < a.B) {
                 floatx4 *dst = out_of(blk, r);
 #ifdef DCS_PROBES
@@ -484,7 +500,11 @@ bf_beamform_i8_kernel(const bf_bacc_args a)
     const uint32_t n_chunks = (a.A + 63u) / 64u;
     auto park = [&](int h, const floatx4 (&f)[4]) {
 #pragma unroll
-        for (int r = 0; r < 4; r++) part[((h * 4 + r) * 4 + kc) * 64u + lane] = floatx4{f[0][r], f[1][r], f[2][r], f[3][r]};
+        for (int r = 0; r < 4; r++) {
+            floatx4 o = {f[0][r], f[1][r], f[2][r], f[3][r]};
+            if (nan_re | nan_im) poison(r, o); // the chunk's NaN rows reach the sum through its partial sums
+            part[((h * 4 + r) * 4 + kc) * 64u + lane] = o;
+        }
     };
     auto gather = [&](auto whole, int h, uint32_t blk) {
         floatx4 o = part[((h * 4 + wave) * 4 + 0) * 64u + lane];
@@ -570,6 +590,11 @@ bf_beamform_i8_kernel(const bf_bacc_args a)
     } else
 #endif
     if ((shared_w ? bw < a.B : !idle) && has_chunk) make_coefficients();
+    if (cls == DCS_CLASS_SLOW) { // bit i: result row i (lanes i, i + 16, i + 32, i + 48 hold its antennas) has a non-finite coefficient
+        const uint64_t br = __builtin_amdgcn_ballot_w64(bad_re), bi = __builtin_amdgcn_ballot_w64(bad_im);
+        nan_re = (uint32_t)((br | (br >> 16) | (br >> 32) | (br >> 48)) & 0xffffu);
+        nan_im = (uint32_t)((bi | (bi >> 16) | (bi >> 32) | (bi >> 48)) & 0xffffu);
+    }
     if (STAGED) {
         uint32_t *wx = reinterpret_cast<uint32_t *>(staged + a.share_off) + bt * (4u * 6u * 64u) + lane; // [tile][q][plane][lane]
         if (shared_w && bw < a.B) {

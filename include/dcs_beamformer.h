@@ -237,7 +237,8 @@ int dcs_bf_generate_and_beamform_dt(dcs_bf_context *ctx, const float *dt, uint32
  * coefficient held: sum += coeff * sample, whose partial sums round at every antenna) -- and within
  * 4e-5 * nr_stations of that loop in the worst case (every sample at full scale and every error aligned: 1 ulp of
  * the coefficient + the quantisation + the roundings of either side, 3e-7 * 128 per antenna; typically 10 x less),
- * against the reference's tolerance of 1e-1 (runBeamformerTests.cpp:15).
+ * against the reference's tolerance of 1e-1 (runBeamformerTests.cpp:15).  A coefficient that is not finite (an infinite or
+ * NaN delay value) makes every sample of its beam NaN in the plane concerned, as in the verifier's sum (NaN * 0 = NaN).
  * dcs_bf_tuning.math_mode bit 3 selects the other form: v_mfma_f32_16x16x4_f32, exact fp32 products
  * accumulated as an fma chain in antenna order (differs from the verifier's loop by the chain's single
  * roundings only; same bound; 1/32 of the int8 pipe's rate).  nr_stations <= 256; d_antenna 16-byte aligned.

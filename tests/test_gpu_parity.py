@@ -1489,6 +1489,40 @@ def test_beamform_accumulated_seeded_fuzz(gpu, oracle):
         d_beams.free()
 
 
+@pytest.mark.parametrize("math_mode", [0, 8])
+@pytest.mark.parametrize("A,B,C,nt", [(20, 18, 3, 32), (64, 16, 2, 64), (130, 20, 2, 32), (256, 5, 1, 16)])
+def test_beamform_accumulated_non_finite_coefficients(gpu, oracle, A, B, C, nt, math_mode):
+    """An infinite or NaN delay value makes that pair's coefficient NaN and, with it, every sample of its beam (the plane
+    concerned) in the verifier's sum: NaN * 0 = NaN.  Both forms give NaN in exactly those places -- the fixed-point form,
+    whose digits cannot hold a NaN, by marking the rows -- and the other beams are unaffected."""
+    from dc_sand_amd import BeamformerParameters
+    from dc_sand_amd.generator import SteeringCoefficientGenerator
+
+    bp = BeamformerParameters(NR_CHANNELS=C, NR_STATIONS=A, NR_BEAMS=B, NR_SAMPLES_PER_CHANNEL=nt)
+    op = oracle.params_from(bp)
+    table = rand_table(bp.n_pairs, seed=5)  # [b*A + a]
+    table["fDelayRate_sps"][2 * A + min(3, A - 1)] = np.inf       # beam 2
+    table["fPhase_rad"][(B - 1) * A + A - 1] = np.nan              # the last beam, the last antenna
+    ant = np.random.default_rng(1).integers(-128, 128, size=(C, nt // 16, A, 16, 2), dtype=np.int8)
+    dt = np.float32(0.25)
+    exp = oracle.beamform_accumulated(op, table, dt, nt, ant)
+    assert np.isnan(exp).any() and not np.isnan(exp).all()
+    g = SteeringCoefficientGenerator(bp)
+    g.upload_delays(table)
+    if math_mode:
+        g.set_tuning(math_mode=math_mode)
+    d_ant = gpu.mem_alloc(ant.nbytes)
+    gpu.memcpy_htod(d_ant, ant)
+    d_beams = gpu.mem_alloc(exp.nbytes)
+    g.beamform_accumulated(d_ant, ant.nbytes, d_beams, exp.nbytes, nt, dt_coeff=float(dt))
+    got = np.empty_like(exp)
+    gpu.memcpy_dtoh(got, d_beams)
+    assert np.array_equal(np.isnan(exp), np.isnan(got))
+    fin = ~np.isnan(exp)
+    assert np.abs(np.where(fin, got - exp, 0)).max() <= 4e-5 * A + 1e-6
+    g.close()
+
+
 def test_beamform_accumulated_slow_class_and_limits(gpu, oracle):
     """A pair outside the fast path's range sends the coefficient generation down the slow branch (IEEE divide, fp64
     sincos); more than 256 antennas and sample counts that are not whole 16-sample blocks are refused."""
