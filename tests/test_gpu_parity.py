@@ -1154,6 +1154,19 @@ def test_non_finite_delay_values_give_the_verifiers_nans(gpu, oracle, kernel):
     fin = ~np.isnan(exp)
     mx, n_over, _ = oracle.max_ulp(np.where(fin, got, 0).astype(np.float32), np.where(fin, exp, 0).astype(np.float32), 1)
     assert n_over == 0, mx
+    if kernel != 0:  # the packed binary16 output, both arithmetic forms: NaN in the same places, the rest RN-even / within 1 ulp
+        nb16 = g.output_bytes(0, dts.size)
+        for math_mode in (0, 4):
+            g.set_tuning(math_mode=math_mode) if math_mode else g.set_tuning()
+            g.generate_dt(buf, nb16, dts, kernel=kernel, bitwidth=0)
+            h16 = np.empty(got.shape, dtype=np.float16)
+            gpu.memcpy_dtoh(h16, buf)
+            assert np.array_equal(np.isnan(h16), np.isnan(exp)), math_mode
+            want = np.where(fin, exp, 0).astype(np.float16).view(np.uint16).astype(np.int32)
+            have = np.where(fin, h16, 0).astype(np.float16).view(np.uint16).astype(np.int32)
+            def ordered(u):
+                return np.where(u & 0x8000, -(u & 0x7FFF), u & 0x7FFF)
+            assert np.abs(ordered(have) - ordered(want)).max() <= 1, math_mode
     g.close()
 
 
