@@ -1170,6 +1170,46 @@ def test_non_finite_delay_values_give_the_verifiers_nans(gpu, oracle, kernel):
     g.close()
 
 
+def test_seeded_fuzz_of_the_sampling_period_fft_size_and_channel_count(gpu, oracle):
+    """40 seeded random PARAMETER sets -- SAMPLING_PERIOD from 1e-9 to 1e-5 s, FFT_SIZE 256 .. 65536, channel counts that
+    are not powers of two -- i.e. forty different divisors Ts * C for the divide by the launch constant (whose 3-operation
+    form dcs_bf_create verifies per divisor) and forty different time grids: every launch shape by time index, fp32 within
+    1 ULP of the verifier, fp16 the RN-even image of it."""
+    from dc_sand_amd import BeamformerParameters
+    from dc_sand_amd.generator import SteeringCoefficientGenerator
+
+    rng = np.random.default_rng(20261008)
+    for case in range(40):
+        Ts = float(10.0 ** rng.uniform(-9, -5))
+        fft = int(2 ** rng.integers(8, 17))
+        A, B = int(rng.integers(1, 6)), int(rng.integers(1, 30))
+        C = int(rng.choice([1, 2, 3, 7, 48, 100, 257, 1000, 1023, 1025])) if case % 2 else int(rng.integers(1, 300))
+        bp = BeamformerParameters(NR_CHANNELS=C, NR_STATIONS=A, NR_BEAMS=B, SAMPLING_PERIOD=Ts, FFT_SIZE=fft)
+        op = oracle.params_from(bp)
+        table = rand_table(bp.n_pairs, seed=9000 + case, Ts=Ts)
+        nt = int(rng.integers(1, 4))
+        t0 = int(rng.integers(0, 3000))
+        kernel = int(rng.integers(0, 3))
+        g = SteeringCoefficientGenerator(bp)
+        g.upload_delays(table)
+        nb = g.output_bytes(1, nt)
+        buf = gpu.mem_alloc(nb)
+        g.generate(buf, nb, t0=t0, nt=nt, kernel=kernel)
+        got = np.empty((nt, C, A, B, 2), dtype=np.float32)
+        gpu.memcpy_dtoh(got, buf)
+        exp = oracle.generate(op, table, t0, nt)
+        tag = (case, Ts, fft, A, B, C, nt, t0, kernel)
+        mx, n_over, first = oracle.max_ulp(got, exp, 1)
+        assert n_over == 0, (tag, mx, n_over, first)
+        if kernel != 0:
+            g.generate(buf, g.output_bytes(0, nt), t0=t0, nt=nt, kernel=kernel, bitwidth=0)
+            h16 = np.empty(got.shape, dtype=np.float16)
+            gpu.memcpy_dtoh(h16, buf)
+            assert np.array_equal(h16.view(np.uint16), got.astype(np.float16).view(np.uint16)), tag
+        g.close()
+        buf.free()
+
+
 def test_generate_dt_seeded_fuzz_over_the_whole_time_and_rate_range(gpu, oracle):
     """50 seeded random cases of dcs_bf_generate_dt: fDeltaTime from 1e-7 s to 1e4 s of either sign (and 0), delay
     tables whose rates span nine decades on top of the usual ones -- so that waves land in every class (low-degree,
