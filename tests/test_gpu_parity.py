@@ -1210,6 +1210,58 @@ def test_seeded_fuzz_of_the_sampling_period_fft_size_and_channel_count(gpu, orac
         buf.free()
 
 
+def test_two_contexts_on_two_streams_at_once(gpu, oracle):
+    """The one-stream-at-a-time rule is per CONTEXT (include/dcs_beamformer.h, dcs_bf_create): two contexts, each on its
+    own stream, enqueue launches of every kind turn by turn -- generators in both widths, a streaming graph, both
+    beamformers -- without a host synchronisation in between, and each gets its own results."""
+    from dc_sand_amd import BeamformerParameters
+    from dc_sand_amd.generator import SteeringCoefficientGenerator, delta_times
+
+    shapes = [BeamformerParameters(NR_CHANNELS=300, NR_STATIONS=8, NR_BEAMS=40, NR_SAMPLES_PER_CHANNEL=32),
+              BeamformerParameters(NR_CHANNELS=77, NR_STATIONS=66, NR_BEAMS=24, NR_SAMPLES_PER_CHANNEL=32)]
+    ctx = []
+    for i, bp in enumerate(shapes):
+        g = SteeringCoefficientGenerator(bp)
+        st = gpu.Stream()
+        table = rand_table(bp.n_pairs, seed=400 + i)
+        g.upload_delays(table, stream=st)
+        nt = 3
+        nb = g.output_bytes(1, nt)
+        ant = np.random.default_rng(i).integers(-128, 128, size=(bp.NR_CHANNELS, 2, bp.NR_STATIONS, 16, 2), dtype=np.int8)
+        d_ant = gpu.mem_alloc(ant.nbytes)
+        gpu.memcpy_htod(d_ant, ant, stream=st)
+        ctx.append(dict(bp=bp, g=g, st=st, table=table, nt=nt, nb=nb, out32=gpu.mem_alloc(nb), out16=gpu.mem_alloc(nb // 2), ant=ant, d_ant=d_ant,
+                        acc=gpu.mem_alloc(bp.NR_BEAMS * bp.NR_CHANNELS * 32 * 8), fused=gpu.mem_alloc(bp.NR_BEAMS * bp.NR_CHANNELS * 32 * 8)))
+    for rep in range(3):  # turn by turn, nothing waits
+        for c in ctx:
+            c["g"].generate(c["out32"], c["nb"], t0=5, nt=c["nt"], stream=c["st"])
+        for c in ctx:
+            c["g"].generate(c["out16"], c["nb"] // 2, t0=5, nt=c["nt"], bitwidth=0, stream=c["st"])
+        for c in ctx:
+            c["g"].beamform_accumulated(c["d_ant"], c["ant"].nbytes, c["acc"], c["bp"].NR_BEAMS * c["bp"].NR_CHANNELS * 32 * 8, 32, t_coeff=9, stream=c["st"])
+        for c in ctx:
+            c["g"].generate_and_beamform(c["d_ant"], c["ant"].nbytes, c["fused"], c["bp"].NR_BEAMS * c["bp"].NR_CHANNELS * 32 * 8, t0=0, nt=32, stream=c["st"])
+    for c in ctx:
+        c["st"].synchronize()
+        bp, op = c["bp"], oracle.params_from(c["bp"])
+        got = np.empty((c["nt"], bp.NR_CHANNELS, bp.NR_STATIONS, bp.NR_BEAMS, 2), dtype=np.float32)
+        gpu.memcpy_dtoh(got, c["out32"])
+        table_ab = c["table"]
+        _check(oracle, got, oracle.generate(op, table_ab, 5, c["nt"]))
+        h16 = np.empty(got.shape, dtype=np.float16)
+        gpu.memcpy_dtoh(h16, c["out16"])
+        assert np.array_equal(h16.view(np.uint16), got.astype(np.float16).view(np.uint16))
+        exp_acc = oracle.beamform_accumulated(op, c["table"], delta_times(bp, 9, 1)[0], 32, c["ant"])
+        acc = np.empty_like(exp_acc)
+        gpu.memcpy_dtoh(acc, c["acc"])
+        assert np.abs(acc - exp_acc).max() <= 4e-5 * bp.NR_STATIONS + 1e-6
+        exp_f = oracle.beamform(op, c["table"], 32, c["ant"])
+        fused = np.empty_like(exp_f)
+        gpu.memcpy_dtoh(fused, c["fused"])
+        assert np.abs(fused - exp_f).max() <= 2e-5 * bp.NR_STATIONS + 1e-6
+        c["g"].close()
+
+
 def test_generate_dt_seeded_fuzz_over_the_whole_time_and_rate_range(gpu, oracle):
     """50 seeded random cases of dcs_bf_generate_dt: fDeltaTime from 1e-7 s to 1e4 s of either sign (and 0), delay
     tables whose rates span nine decades on top of the usual ones -- so that waves land in every class (low-degree,
