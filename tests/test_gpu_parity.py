@@ -1210,6 +1210,67 @@ def test_seeded_fuzz_of_the_sampling_period_fft_size_and_channel_count(gpu, orac
         buf.free()
 
 
+def test_streaming_seeded_fuzz_of_tick_kinds_slabs_and_table_updates(gpu, oracle):
+    """12 seeded streams (hipGraph replay, BASELINE configs[4]'s plumbing) x 8 ticks each: a random channel slab and
+    output width per stream, every tick by time index, by fDeltaTime or by a (current, reference) pair, a new delay table
+    landing with some of the ticks (double-buffered), the slab read back after every tick: fp32 within 1 ULP of the
+    verifier at that tick's time and table, fp16 within one binary16 ulp of its RN-even image."""
+    from dc_sand_amd import BeamformerParameters
+    from dc_sand_amd.generator import SteeringCoefficientGenerator, delta_times
+
+    rng = np.random.default_rng(20261009)
+    for case in range(12):
+        A, B, C = int(rng.integers(1, 7)), int(rng.integers(1, 40)), int(rng.integers(2, 60))
+        bp = BeamformerParameters(NR_CHANNELS=C, NR_STATIONS=A, NR_BEAMS=B)
+        op = oracle.params_from(bp)
+        table = rand_table(bp.n_pairs, seed=11000 + case)
+        c0 = int(rng.integers(0, C))
+        nc = int(rng.integers(1, C - c0 + 1))
+        bw = int(rng.integers(0, 2))
+        g = SteeringCoefficientGenerator(bp)
+        st = gpu.Stream()
+        g.upload_delays(table, stream=st)
+        nbytes = nc * bp.n_pairs * (8 if bw == 1 else 4)
+        buf = gpu.mem_alloc(nbytes)
+        s_ = g.stream_begin(buf, nbytes, c0, nc, st, bitwidth=bw)
+        for tick in range(8):
+            new = None
+            if rng.integers(0, 3) == 0:
+                table = rand_table(bp.n_pairs, seed=12000 + 10 * case + tick)
+                new = table
+            kind = int(rng.integers(0, 3))
+            if kind == 0:
+                t = int(rng.integers(0, 5000))
+                s_.tick(t, new_table=new)
+                dt = delta_times(bp, t, 1)[0]
+            elif kind == 1:
+                dt = np.float32(rng.uniform(-2.0, 2.0))
+                s_.tick_dt(float(dt), new_table=new)
+            else:
+                ref = (int(rng.integers(0, 10 ** 6)), int(rng.integers(0, 10 ** 9)))
+                cur = (ref[0] + int(rng.integers(0, 3)), int(rng.integers(0, 10 ** 9)))
+                s_.tick_at(cur, ref, new_table=new)
+                dt = oracle.ts_diff(ref, cur)
+            st.synchronize()
+            exp = oracle.generate_dt(op, table, [dt], c0, nc)[0]
+            tag = (case, tick, kind, A, B, C, c0, nc, bw, float(dt))
+            if bw == 1:
+                got = np.empty(exp.shape, dtype=np.float32)
+                gpu.memcpy_dtoh(got, buf)
+                mx, n_over, first = oracle.max_ulp(got, exp, 1)
+                assert n_over == 0, (tag, mx, n_over, first)
+            else:
+                h16 = np.empty(exp.shape, dtype=np.float16)
+                gpu.memcpy_dtoh(h16, buf)
+                have = h16.view(np.uint16).astype(np.int32)
+                want = exp.astype(np.float16).view(np.uint16).astype(np.int32)
+                ordered = lambda u: np.where(u & 0x8000, -(u & 0x7FFF), u & 0x7FFF)
+                assert np.abs(ordered(have) - ordered(want)).max() <= 1, tag
+        s_.end()
+        g.close()
+        buf.free()
+
+
 def test_two_contexts_on_two_streams_at_once(gpu, oracle):
     """The one-stream-at-a-time rule is per CONTEXT (include/dcs_beamformer.h, dcs_bf_create): two contexts, each on its
     own stream, enqueue launches of every kind turn by turn -- generators in both widths, a streaming graph, both
