@@ -533,6 +533,9 @@ bf_geom shape_default_geometry(const dcs_bf_context *c, bool out16, uint32_t nc,
             g.wpc = 0;
         }
         const uint64_t bytes = (uint64_t)nt * nc * c->n_pairs * 8u;
+        // launches of a quarter of a GiB up to the terms-table variant's 2 GiB: 12 channels WITHOUT the residency limit
+        // was among the best two geometries on four boxes of four (64 x 256 x 8192: 905-912 Gcoeff/s against 872-887 with it)
+        if (bytes >= (256ull << 20) && bytes < (2ull << 30) && tiles < 2048u) g.wpc = 0;
         if (bytes <= (32ull << 20) && tiled_blocks(c->n_pairs, false, 1, g.cpb, nc, nt) > 1024u) {
             g.tpb = 2;
             g.cpb = 16u;
@@ -552,12 +555,21 @@ bf_geom shape_default_geometry(const dcs_bf_context *c, bool out16, uint32_t nc,
             g.wpc = 6;
         }
     }
-    // rows of at most 4 tiles (<= 4 KiB): consecutive rows are nearly adjacent in memory, and a workgroup does
-    // better writing 16 of them, two tiles wide (64 KiB contiguous), than a short walk
+    // rows of at most 4 tiles (<= 4 KiB): consecutive rows are nearly adjacent in memory, and in a small launch a
+    // workgroup does better writing 16 of them, two tiles wide (64 KiB contiguous), than a short walk; a large launch of
+    // such rows (16 x 16 x 32768: 128 MiB) is an ordinary store stream again, best at 10 channels x 6 workgroups per CU
+    // on both boxes it was swept on (profiles/r02_autotune.md)
     if (!out16 && (c->n_pairs + 127u) / 128u <= 4u) {
-        g.tpb = c->n_pairs > 128u ? 2 : 1;
-        g.cpb = 16u;
-        g.wpc = 0;
+        const uint64_t bytes = (uint64_t)nt * nc * c->n_pairs * 8u;
+        if (bytes <= (32ull << 20)) {
+            g.tpb = c->n_pairs > 128u ? 2 : 1;
+            g.cpb = 16u;
+            g.wpc = 0;
+        } else {
+            g.tpb = 1;
+            g.cpb = 10u;
+            g.wpc = 6;
+        }
     }
     return g;
 }

@@ -251,8 +251,8 @@ int dcs_bf_beamform_accumulated_dt(dcs_bf_context *ctx, float dt_coeff, uint32_t
 /* Launch-geometry knobs (all 0 / NULL = the library's shape-aware defaults, DESIGN.md "launch
  * geometry": per launch the library looks at the tiles per row, the workgroups the launch makes and
  * its bytes -- fp32: 1 tile x 12 channels per workgroup and at most 6 workgroups per CU when there is
- * plenty of work, 10 channels without limit for rows of >= 2048 tiles, 2 tiles x 16 channels for
- * launch-bound tensors of <= 32 MiB; fp16: 128 channels, fewer while the chip would be left under 2048
+ * plenty of work (no limit for launches of 256 MiB - 2 GiB), 10 channels without limit for rows of >= 2048 tiles,
+ * 2 tiles x 16 channels for launch-bound tensors of <= 32 MiB; fp16: 128 channels, fewer while the chip would be left under 2048
  * workgroups; no residency limit when every workgroup is resident at once).  Two forms of the
  * MULTIPLE_CHANNELS_AND_TIMESTAMPS generator exist and give identical bits:
  *   "tiled": a workgroup (4 waves) keeps its pairs' terms in registers and walks chan_per_block
