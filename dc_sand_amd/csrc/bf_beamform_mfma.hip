@@ -70,7 +70,8 @@ __global__ void __launch_bounds__(kBlock) bf_beamform_acc_kernel(const bf_bacc_a
     const uint32_t bt = wave % NBT, slot = wave / NBT;
     const uint32_t lm = lane & 15u, lg = lane >> 4;
 
-    const uint32_t cls = a.flags[0]; // highest pair class of the table (bf_bform_terms_kernel)
+    const uint32_t fw = a.flags[0]; // (epoch << 2) | highest pair class of the table (bf_bform_terms_kernel)
+    const uint32_t cls = (fw >> 2) == a.epoch ? (fw & 3u) : DCS_CLASS_FAST_LOW;
     const float fChan = (float)c;
     const float D = a.k.fDenominator, y = a.k.fRcpDenominator;
     // one coefficient through the class's path (slow: IEEE divide + fp64 sincos; rare, workgroup-uniform)
@@ -272,7 +273,8 @@ bf_beamform_i8_kernel(const bf_bacc_args a)
                                              16, 0, 0);
     }
 
-    const uint32_t cls = a.flags[0];
+    const uint32_t fw = a.flags[0]; // (epoch << 2) | highest pair class of the table (bf_bform_terms_kernel)
+    const uint32_t cls = (fw >> 2) == a.epoch ? (fw & 3u) : DCS_CLASS_FAST_LOW;
     const float fChan = (float)c;
     const float D = a.k.fDenominator, y = a.k.fRcpDenominator;
 

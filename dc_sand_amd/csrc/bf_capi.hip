@@ -111,6 +111,7 @@ struct dcs_bf_context {
     uint32_t terms_steps;   // time steps the table holds
     float *d_terms;         // [terms_steps][pairs_pad][2]; allocated on first use (ensure_terms)
     uint32_t *d_flags;      // [terms_steps][pairs_pad/64]
+    uint32_t flag_epoch;    // the beamformers' class words are tagged with the call's number instead of being zeroed per call
     // the terms-table variant of the tiled form (large launches of <= kTermsInline time steps): its own small
     // table, allocated with the context so that those launches stay capturable
     float *d_tt_terms;      // [kTermsInline][pairs_pad][2]
@@ -673,13 +674,30 @@ int launch_tiled(dcs_bf_context *c, bool out16, const float *dt_dev, float dt0, 
     return (int)hipLaunchKernel(l.func, l.grid, l.block, params, l.shared, stream);
 }
 
+// The number of this beamformer call for its class words (bf_bform_terms_args::epoch): counts up, and starts again --
+// behind a clearing of the words -- before it would run out of the 30 bits it has.
+int next_flag_epoch(dcs_bf_context *c, hipStream_t s, uint32_t *epoch)
+{
+    if (c->flag_epoch >= (1u << 30) - 2u) {
+        DCS_TRY(hipMemsetAsync(c->d_flags, 0, (size_t)c->terms_steps * (c->pairs_pad / 64u) * 4u, s));
+        c->flag_epoch = 0;
+    }
+    *epoch = ++c->flag_epoch;
+    return DCS_OK;
+}
+
 // The terms table (up to 64 MiB) is only needed by the rows form and the fused kernel:
 // allocate it when one of them is first used.  Not capturable (hipMalloc), like those paths.
 int ensure_terms(dcs_bf_context *c)
 {
     if (c->d_terms && c->d_flags) return DCS_OK;
     if (!c->d_terms) DCS_TRY(hipMalloc((void **)&c->d_terms, (size_t)c->terms_steps * c->pairs_pad * 8u));
-    if (!c->d_flags) DCS_TRY(hipMalloc((void **)&c->d_flags, (size_t)c->terms_steps * (c->pairs_pad / 64u) * 4u));
+    if (!c->d_flags) {
+        const size_t nb = (size_t)c->terms_steps * (c->pairs_pad / 64u) * 4u;
+        DCS_TRY(hipMalloc((void **)&c->d_flags, nb));
+        DCS_TRY(hipMemset(c->d_flags, 0, nb)); // epoch 0: no call has that number
+        c->flag_epoch = 0;
+    }
     return DCS_OK;
 }
 
@@ -943,12 +961,17 @@ int beamform_impl(dcs_bf_context *c, const dt_source &src, uint32_t nt, const in
         const float *dt_dev = nullptr;
         int st = stage_dt(c, src, done, n, s, &dt_dev);
         if (st != DCS_OK) return st;
-        DCS_TRY(hipMemsetAsync(c->d_flags, 0, (size_t)n * sizeof(uint32_t), s));
+        uint32_t epoch = 0;
+        {
+            const int st_ep = next_flag_epoch(c, s, &epoch);
+            if (st_ep != DCS_OK) return st_ep;
+        }
         bf_bform_terms_args ta;
         std::memset(&ta, 0, sizeof(ta));
         ta.delays = c->d_table[c->cur];
         ta.terms = c->d_terms;
         ta.flags = c->d_flags;
+        ta.epoch = epoch;
         ta.dt_dev = dt_dev;
         ta.n_pairs = c->n_pairs;
         ta.A = A;
@@ -960,6 +983,7 @@ int beamform_impl(dcs_bf_context *c, const dt_source &src, uint32_t nt, const in
         std::memset(&a, 0, sizeof(a));
         a.terms = c->d_terms;
         a.flags = c->d_flags;
+        a.epoch = epoch;
         a.ant = d_antenna;
         a.beams = d_beams;
         a.A = A;
@@ -1018,12 +1042,17 @@ int beamform_acc_impl(dcs_bf_context *c, const dt_source &src, uint32_t nt, cons
     const float *dt_dev = nullptr;
     int st = stage_dt(c, src, 0, 1, s, &dt_dev); // ONE coefficient time for the whole block of samples
     if (st != DCS_OK) return st;
-    DCS_TRY(hipMemsetAsync(c->d_flags, 0, sizeof(uint32_t), s));
+    uint32_t epoch = 0;
+    {
+        const int st_ep = next_flag_epoch(c, s, &epoch);
+        if (st_ep != DCS_OK) return st_ep;
+    }
     bf_bform_terms_args ta;
     std::memset(&ta, 0, sizeof(ta));
     ta.delays = c->d_table[c->cur];
     ta.terms = c->d_terms;
     ta.flags = c->d_flags;
+    ta.epoch = epoch;
     ta.dt_dev = dt_dev;
     ta.n_pairs = c->n_pairs;
     ta.A = A;
@@ -1035,6 +1064,7 @@ int beamform_acc_impl(dcs_bf_context *c, const dt_source &src, uint32_t nt, cons
     std::memset(&a, 0, sizeof(a));
     a.terms = c->d_terms;
     a.flags = c->d_flags;
+    a.epoch = epoch;
     a.ant = d_antenna;
     a.beams = d_beams;
     a.A = A;

@@ -98,7 +98,8 @@ hipError_t bf_launch_rows(const bf_rows_args &a, bool out16, int waves_per_block
 struct bf_bform_terms_args {
     const dcs_delay_vals *delays; // [B][A]
     float *terms;                 // [nt][A][B][2]
-    uint32_t *flags;              // [nt], zeroed by the caller; |= 1 if any pair is slow at t
+    uint32_t *flags;              // [nt]: atomicMax of (epoch << 2) | class; words of earlier epochs count as the lowest class
+    uint32_t epoch;               // this call's number (1 .. 2^30 - 2), from the context
     const float *dt_dev;          // [nt]
     uint32_t n_pairs, A, B, nt;
     dcs_bf_consts k;
@@ -107,7 +108,8 @@ hipError_t bf_launch_bform_terms(const bf_bform_terms_args &a, hipStream_t strea
 
 struct bf_beamform_args {
     const float *terms;    // [nt16*16][A][B][2] for this launch's time steps
-    const uint32_t *flags; // [nt16*16]
+    const uint32_t *flags; // [nt16*16], epoch-tagged (bf_bform_terms_args)
+    uint32_t epoch;
     const int8_t *ant;     // [C][nt16_total][A][16][2]
     float *beams;          // [C][nt16_total][B][16][2]
     uint32_t A, B, C;
@@ -124,7 +126,8 @@ hipError_t bf_launch_beamform(const bf_beamform_args &a, hipStream_t stream);
 // (terms table [A][B] from bf_launch_bform_terms with nt = 1) applied to nT16 blocks of 16 samples.
 struct bf_bacc_args {
     const float *terms;    // [A][B][2]
-    const uint32_t *flags; // [1]: highest pair class of the table
+    const uint32_t *flags; // [1]: (epoch << 2) | highest pair class of the table
+    uint32_t epoch;
     const int8_t *ant;     // [C][nT16][A][16][2]
     float *beams;          // [C][nT16][B][16][2]
     uint32_t A, B, C, nT16;

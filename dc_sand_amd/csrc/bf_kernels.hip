@@ -480,8 +480,9 @@ __global__ void __launch_bounds__(kBlock) bf_bform_terms_kernel(const bf_bform_t
         *reinterpret_cast<floatx2 *>(a.terms + 2u * ((uint64_t)t * a.n_pairs + (uint64_t)ant * a.B + b)) =
             floatx2{fRate, fPhase0};
     }
-    // flags[t] = highest class at time t (zeroed by the caller)
-    if (cls != DCS_CLASS_FAST_LOW) atomicMax(&a.flags[t], cls);
+    // flags[t] = (epoch << 2) | highest class at time t: the caller numbers its calls, so a word left by an earlier call
+    // (a lower epoch) reads as "nothing above the lowest class yet" and nobody has to zero the words in between
+    if (cls != DCS_CLASS_FAST_LOW) atomicMax(&a.flags[t], (a.epoch << 2) | cls);
 }
 
 // CH channels per pass: a lane's terms load and the LDS sample reads are shared by CH
@@ -504,7 +505,8 @@ __global__ void __launch_bounds__(kBlock) bf_beamform_kernel(const bf_beamform_a
     const bool live = b < a.B;
 
     // highest pair class over these 16 time steps (bf_bform_terms_kernel)
-    const uint32_t fl = a.flags[tex * 16u + (threadIdx.x & 15u)];
+    const uint32_t fw = a.flags[tex * 16u + (threadIdx.x & 15u)];
+    const uint32_t fl = (fw >> 2) == a.epoch ? (fw & 3u) : DCS_CLASS_FAST_LOW; // bf_bform_terms_kernel's epoch-tagged word
     const int slow = __syncthreads_or((int)(fl == DCS_CLASS_SLOW));
     const int high = __syncthreads_or((int)(fl != DCS_CLASS_FAST_LOW));
 
