@@ -958,8 +958,12 @@ int beamform_impl(dcs_bf_context *c, const dt_source &src, uint32_t nt, const in
     if (chunk == 0) return DCS_ERR_UNSUPPORTED;
     for (uint32_t done = 0; done < nt;) {
         const uint32_t n = (nt - done) < chunk ? (nt - done) : chunk;
+        // up to 256 time steps per launch: their fDeltaTime values travel in the terms kernel's arguments (the reference's
+        // block of 256 samples is then two launches and nothing else); longer launches stage a table through pinned memory
         const float *dt_dev = nullptr;
-        int st = stage_dt(c, src, done, n, s, &dt_dev);
+        float dt_val[kDtInline];
+        const bool inl = n <= kDtInline;
+        int st = inl ? fill_dt(c, src, done, n, dt_val) : stage_dt(c, src, done, n, s, &dt_dev);
         if (st != DCS_OK) return st;
         uint32_t epoch = 0;
         {
@@ -978,7 +982,7 @@ int beamform_impl(dcs_bf_context *c, const dt_source &src, uint32_t nt, const in
         ta.B = B;
         ta.nt = n;
         ta.k = c->k;
-        DCS_TRY(bf_launch_bform_terms(ta, s));
+        DCS_TRY(bf_launch_bform_terms(ta, inl ? dt_val : nullptr, s));
         bf_beamform_args a;
         std::memset(&a, 0, sizeof(a));
         a.terms = c->d_terms;
@@ -1039,8 +1043,8 @@ int beamform_acc_impl(dcs_bf_context *c, const dt_source &src, uint32_t nt, cons
         int st_alloc = ensure_terms(c);
         if (st_alloc != DCS_OK) return st_alloc;
     }
-    const float *dt_dev = nullptr;
-    int st = stage_dt(c, src, 0, 1, s, &dt_dev); // ONE coefficient time for the whole block of samples
+    float dt_coeff = 0.0f; // ONE coefficient time for the whole block of samples: by value, in the kernel arguments
+    int st = fill_dt(c, src, 0, 1, &dt_coeff);
     if (st != DCS_OK) return st;
     uint32_t epoch = 0;
     {
@@ -1053,13 +1057,14 @@ int beamform_acc_impl(dcs_bf_context *c, const dt_source &src, uint32_t nt, cons
     ta.terms = c->d_terms;
     ta.flags = c->d_flags;
     ta.epoch = epoch;
-    ta.dt_dev = dt_dev;
+    ta.dt_dev = nullptr;
+    ta.dt0 = dt_coeff;
     ta.n_pairs = c->n_pairs;
     ta.A = A;
     ta.B = B;
     ta.nt = 1;
     ta.k = c->k;
-    DCS_TRY(bf_launch_bform_terms(ta, s));
+    DCS_TRY(bf_launch_bform_terms(ta, nullptr, s));
     bf_bacc_args a;
     std::memset(&a, 0, sizeof(a));
     a.terms = c->d_terms;

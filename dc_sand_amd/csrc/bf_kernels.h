@@ -100,11 +100,18 @@ struct bf_bform_terms_args {
     float *terms;                 // [nt][A][B][2]
     uint32_t *flags;              // [nt]: atomicMax of (epoch << 2) | class; words of earlier epochs count as the lowest class
     uint32_t epoch;               // this call's number (1 .. 2^30 - 2), from the context
-    const float *dt_dev;          // [nt]
+    const float *dt_dev;          // [nt], or nullptr: nt == 1 and fDeltaTime is dt0 (by value: nothing to stage)
+    float dt0;
     uint32_t n_pairs, A, B, nt;
     dcs_bf_consts k;
 };
-hipError_t bf_launch_bform_terms(const bf_bform_terms_args &a, hipStream_t stream);
+struct bf_bform_terms_args_inl {
+    bf_bform_terms_args a;
+    float dt_inline[kDtInline];
+};
+// dt_inline: nullptr (fDeltaTime from a.dt_dev, or a.dt0 when nt == 1), or a.nt <= kDtInline values that travel in the
+// kernel arguments
+hipError_t bf_launch_bform_terms(const bf_bform_terms_args &a, const float *dt_inline, hipStream_t stream);
 
 struct bf_beamform_args {
     const float *terms;    // [nt16*16][A][B][2] for this launch's time steps

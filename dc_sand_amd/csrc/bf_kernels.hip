@@ -461,8 +461,15 @@ __global__ void __launch_bounds__(kBlock) bf_terms_kernel(const bf_terms_args a)
 // lines per antenna (L2-resident, reused by every channel); the int8 samples of
 // one (channel, 16 times) block are staged in LDS once per channel.
 // ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(kBlock) bf_bform_terms_kernel(const bf_bform_terms_args a)
+template <bool INL> // INL: fDeltaTime of up to kDtInline time steps by value, behind the arguments proper
+__global__ void __launch_bounds__(kBlock) bf_bform_terms_kernel(const std::conditional_t<INL, bf_bform_terms_args_inl, bf_bform_terms_args> args)
 {
+    const bf_bform_terms_args &a = [&]() -> const bf_bform_terms_args & {
+        if constexpr (INL)
+            return args.a;
+        else
+            return args;
+    }();
     const uint32_t p = blockIdx.x * kBlock + threadIdx.x; // table index b*A + a
     const uint32_t t = blockIdx.y;
     uint32_t cls = DCS_CLASS_FAST_LOW;
@@ -474,7 +481,12 @@ __global__ void __launch_bounds__(kBlock) bf_bform_terms_kernel(const bf_bform_t
         d.fPhase_rad = raw.z;
         d.fPhaseRate_radps = raw.w;
         float fRate, fPhase0;
-        dcs_pair_terms(d, a.dt_dev[t], a.k.dHalfChannels, a.k.dDenominator, &fRate, &fPhase0);
+        float dt;
+        if constexpr (INL)
+            dt = args.dt_inline[t];
+        else
+            dt = a.dt_dev ? a.dt_dev[t] : a.dt0;
+        dcs_pair_terms(d, dt, a.k.dHalfChannels, a.k.dDenominator, &fRate, &fPhase0);
         cls = dcs_pair_class(fRate, fPhase0, a.k.fRotBoundScale, a.k.fLowDegLimit);
         const uint32_t b = p / a.A, ant = p - b * a.A;
         *reinterpret_cast<floatx2 *>(a.terms + 2u * ((uint64_t)t * a.n_pairs + (uint64_t)ant * a.B + b)) =
@@ -890,12 +902,27 @@ hipError_t bf_warm_module()
     return hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(&bf_gather_beams_kernel));
 }
 
-hipError_t bf_launch_bform_terms(const bf_bform_terms_args &a, hipStream_t stream)
+hipError_t bf_launch_bform_terms(const bf_bform_terms_args &a, const float *dt_inline, hipStream_t stream)
 {
     if (a.nt == 0 || a.n_pairs == 0) return hipSuccess;
-    if (a.nt > 65535u || a.dt_dev == nullptr) return hipErrorInvalidValue;
+    if (a.nt > 65535u) return hipErrorInvalidValue;
     const dim3 grid((a.n_pairs + kBlock - 1) / kBlock, a.nt);
-    hipLaunchKernelGGL(bf_bform_terms_kernel, grid, dim3(kBlock), 0, stream, a);
+    if (dt_inline != nullptr && a.nt > 1u) { // the times travel in the kernel arguments: nothing is staged
+        if (a.nt > kDtInline) return hipErrorInvalidValue;
+        bf_bform_terms_args_inl ai;
+        ai.a = a;
+        std::memcpy(ai.dt_inline, dt_inline, (size_t)a.nt * sizeof(float));
+        hipLaunchKernelGGL(bf_bform_terms_kernel<true>, grid, dim3(kBlock), 0, stream, ai);
+        return hipGetLastError();
+    }
+    bf_bform_terms_args b = a;
+    if (dt_inline != nullptr) {
+        b.dt_dev = nullptr;
+        b.dt0 = dt_inline[0];
+    } else if (a.dt_dev == nullptr && a.nt != 1u) {
+        return hipErrorInvalidValue;
+    }
+    hipLaunchKernelGGL(bf_bform_terms_kernel<false>, grid, dim3(kBlock), 0, stream, b);
     return hipGetLastError();
 }
 

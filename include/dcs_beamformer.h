@@ -8,10 +8,11 @@
  * DCS_ERR_* codes below) and never exits, throws or prints.  All device work is
  * enqueued on the caller's hipStream_t (passed as void*, NULL = the null
  * stream) so the calls can be captured in a hipGraph (dcs_bf_generate /
- * dcs_bf_generate_slab in the default tiled form for up to 256 time steps per
- * call: longer calls, the rows form and the fused kernel stage tables through
- * pinned memory or allocate on first use and are not capturable); nothing here
- * starts host threads.
+ * dcs_bf_generate_slab in the default tiled form and the beamformers, for up to
+ * 256 time steps per call -- their fDeltaTime values travel in the kernel
+ * arguments; the beamformers after a first plain call, which allocates their
+ * terms table -- ; longer calls and the rows form stage tables through pinned
+ * memory and are not capturable); nothing here starts host threads.
  *
  * Each declaration cites the reference interface it replaces (paths relative
  * to the reference root; "BCT" = beamformer_coefficient_generator/
@@ -212,7 +213,7 @@ int dcs_bf_generate_at(dcs_bf_context *ctx, int kernel, int bitwidth, const stru
  * -- the reference's element-wise product (BeamformerKernels.cu:315-316), not a
  * complex one.  For this entry point the delay table is indexed
  * [beam * nr_stations + antenna] (BCT.cu:311; BeamformerKernels.cu:252).
- * No coefficient tensor is materialised. */
+ * No coefficient tensor is materialised.  Two launches (terms pre-pass, beamformer) per 256 time steps. */
 int dcs_bf_generate_and_beamform(dcs_bf_context *ctx, uint64_t t0, uint32_t nt, const int8_t *d_antenna,
                                  size_t antenna_bytes, float *d_beams, size_t beams_bytes, void *stream);
 
@@ -242,7 +243,8 @@ int dcs_bf_generate_and_beamform_dt(dcs_bf_context *ctx, const float *dt, uint32
  * dcs_bf_tuning.math_mode bit 3 selects the other form: v_mfma_f32_16x16x4_f32, exact fp32 products
  * accumulated as an fma chain in antenna order (differs from the verifier's loop by the chain's single
  * roundings only; same bound; 1/32 of the int8 pipe's rate).  nr_stations <= 256; d_antenna 16-byte aligned.
- * Not capturable (stages one fDeltaTime through pinned memory; allocates its terms table on first use). */
+ * Two launches (terms pre-pass, contraction); capturable once the context's terms table exists (allocated by the
+ * first call of this or of dcs_bf_generate_and_beamform: make one call outside the capture). */
 int dcs_bf_beamform_accumulated(dcs_bf_context *ctx, uint64_t t_coeff, uint32_t nt, const int8_t *d_antenna,
                                 size_t antenna_bytes, float *d_beams, size_t beams_bytes, void *stream);
 int dcs_bf_beamform_accumulated_dt(dcs_bf_context *ctx, float dt_coeff, uint32_t nt, const int8_t *d_antenna,

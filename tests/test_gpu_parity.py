@@ -1689,6 +1689,61 @@ def test_beamform_accumulated_non_finite_coefficients(gpu, oracle, A, B, C, nt, 
     g.close()
 
 
+@pytest.mark.parametrize("A,B", [(64, 16), (130, 20)])
+def test_beamform_accumulated_under_stream_capture(gpu, oracle, A, B):
+    """dcs_bf_beamform_accumulated is two kernel launches and nothing else once the context's terms table exists (its one
+    fDeltaTime travels in the kernel arguments): captured into a hipGraph after a first, plain, call and replayed -- a
+    real-time beamformer re-launching one graph per block of samples."""
+    import ctypes
+
+    from dc_sand_amd import BeamformerParameters
+    from dc_sand_amd.generator import SteeringCoefficientGenerator
+
+    hip = ctypes.CDLL("libamdhip64.so")
+    V = ctypes.c_void_p
+    hip.hipStreamBeginCapture.argtypes = [V, ctypes.c_int]
+    hip.hipStreamEndCapture.argtypes = [V, ctypes.POINTER(V)]
+    hip.hipGraphInstantiate.argtypes = [ctypes.POINTER(V), V, V, V, ctypes.c_size_t]
+    hip.hipGraphLaunch.argtypes = [V, V]
+    hip.hipGraphExecDestroy.argtypes = [V]
+    hip.hipGraphDestroy.argtypes = [V]
+
+    C, nt = 5, 48
+    bp = BeamformerParameters(NR_CHANNELS=C, NR_STATIONS=A, NR_BEAMS=B, NR_SAMPLES_PER_CHANNEL=nt)
+    op = oracle.params_from(bp)
+    table = rand_table(bp.n_pairs, seed=61)
+    rng = np.random.default_rng(7)
+    ant = rng.integers(-128, 128, size=(C, nt // 16, A, 16, 2), dtype=np.int8)
+    dt = np.float32(0.0421)
+    exp = oracle.beamform_accumulated(op, table, dt, nt, ant)
+    g = SteeringCoefficientGenerator(bp)
+    g.upload_delays(table)
+    d_ant = gpu.mem_alloc(ant.nbytes)
+    gpu.memcpy_htod(d_ant, ant)
+    d_beams = gpu.mem_alloc(exp.nbytes)
+    s = gpu.Stream()
+    g.beamform_accumulated(d_ant, ant.nbytes, d_beams, exp.nbytes, nt, dt_coeff=float(dt), stream=s.handle)  # allocates the terms table
+    s.synchronize()
+    assert hip.hipStreamBeginCapture(V(s.handle), 0) == 0
+    g.beamform_accumulated(d_ant, ant.nbytes, d_beams, exp.nbytes, nt, dt_coeff=float(dt), stream=s.handle)
+    graph = V()
+    assert hip.hipStreamEndCapture(V(s.handle), ctypes.byref(graph)) == 0 and graph.value
+    ex = V()
+    assert hip.hipGraphInstantiate(ctypes.byref(ex), graph, None, None, 0) == 0
+    for rep in range(3):
+        ant2 = rng.integers(-128, 128, size=ant.shape, dtype=np.int8)  # new samples, same coefficients: what a replay is for
+        gpu.memcpy_htod(d_ant, ant2, stream=s.handle)
+        gpu.memset(d_beams, 0xFF, exp.nbytes, stream=s.handle)
+        assert hip.hipGraphLaunch(ex, V(s.handle)) == 0
+        s.synchronize()
+        got = np.empty_like(exp)
+        gpu.memcpy_dtoh(got, d_beams)
+        assert np.abs(got - oracle.beamform_accumulated(op, table, dt, nt, ant2)).max() <= 4e-5 * A + 1e-6
+    hip.hipGraphExecDestroy(ex)
+    hip.hipGraphDestroy(graph)
+    g.close()
+
+
 def test_beamform_accumulated_slow_class_and_limits(gpu, oracle):
     """A pair outside the fast path's range sends the coefficient generation down the slow branch (IEEE divide, fp64
     sincos); more than 256 antennas and sample counts that are not whole 16-sample blocks are refused."""
