@@ -616,6 +616,61 @@ def test_fused_seeded_fuzz(gpu, oracle):
         d_beams.free()
 
 
+def test_fused_more_steps_than_ride_in_the_kernel_arguments_and_under_capture(gpu, oracle):
+    """The per-sample fused kernel with 288 > 256 time steps (their fDeltaTime table is staged through pinned memory, two
+    terms launches) and, with 256, captured into a hipGraph after a first plain call and replayed on new samples."""
+    import ctypes
+
+    from dc_sand_amd import BeamformerParameters
+    from dc_sand_amd.generator import SteeringCoefficientGenerator
+
+    A, B, C = 9, 20, 3
+    rng = np.random.default_rng(11)
+    for nt in (288, 256):
+        bp = BeamformerParameters(NR_CHANNELS=C, NR_STATIONS=A, NR_BEAMS=B, NR_SAMPLES_PER_CHANNEL=nt)
+        op = oracle.params_from(bp)
+        table = rand_table(bp.n_pairs, seed=62)
+        ant = rng.integers(-128, 128, size=(C, nt // 16, A, 16, 2), dtype=np.int8)
+        exp = oracle.beamform(op, table, nt, ant)
+        g = SteeringCoefficientGenerator(bp)
+        g.upload_delays(table)
+        d_ant = gpu.mem_alloc(ant.nbytes)
+        gpu.memcpy_htod(d_ant, ant)
+        d_beams = gpu.mem_alloc(exp.nbytes)
+        s = gpu.Stream()
+        g.generate_and_beamform(d_ant, ant.nbytes, d_beams, exp.nbytes, t0=0, nt=nt, stream=s.handle)
+        s.synchronize()
+        got = np.empty_like(exp)
+        gpu.memcpy_dtoh(got, d_beams)
+        assert np.abs(got - exp).max() <= 2e-5 * A + 1e-6
+        if nt == 256:
+            hip = ctypes.CDLL("libamdhip64.so")
+            V = ctypes.c_void_p
+            hip.hipStreamBeginCapture.argtypes = [V, ctypes.c_int]
+            hip.hipStreamEndCapture.argtypes = [V, ctypes.POINTER(V)]
+            hip.hipGraphInstantiate.argtypes = [ctypes.POINTER(V), V, V, V, ctypes.c_size_t]
+            hip.hipGraphLaunch.argtypes = [V, V]
+            hip.hipGraphExecDestroy.argtypes = [V]
+            hip.hipGraphDestroy.argtypes = [V]
+            assert hip.hipStreamBeginCapture(V(s.handle), 0) == 0
+            g.generate_and_beamform(d_ant, ant.nbytes, d_beams, exp.nbytes, t0=0, nt=nt, stream=s.handle)
+            graph = V()
+            assert hip.hipStreamEndCapture(V(s.handle), ctypes.byref(graph)) == 0 and graph.value
+            ex = V()
+            assert hip.hipGraphInstantiate(ctypes.byref(ex), graph, None, None, 0) == 0
+            for rep in range(2):
+                ant2 = rng.integers(-128, 128, size=ant.shape, dtype=np.int8)
+                gpu.memcpy_htod(d_ant, ant2, stream=s.handle)
+                gpu.memset(d_beams, 0xFF, exp.nbytes, stream=s.handle)
+                assert hip.hipGraphLaunch(ex, V(s.handle)) == 0
+                s.synchronize()
+                gpu.memcpy_dtoh(got, d_beams)
+                assert np.abs(got - oracle.beamform(op, table, nt, ant2)).max() <= 2e-5 * A + 1e-6
+            hip.hipGraphExecDestroy(ex)
+            hip.hipGraphDestroy(graph)
+        g.close()
+
+
 def test_fused_harness_and_slow_path(gpu, oracle):
     from dc_sand_amd import BeamformerParameters
     from dc_sand_amd.beamformer_coeff_test import BeamformerCoeffTest, SteeringCoefficientBitWidth as BW, SteeringCoefficientKernel as K
