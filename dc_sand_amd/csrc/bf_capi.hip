@@ -360,6 +360,7 @@ int dcs_bf_create(const dcs_bf_params *p, dcs_bf_context **out)
     do {
         if ((st = (int)hipGetDevice(&c->device)) != 0) break;
         if ((st = (int)bf_warm_module()) != 0) break; // load the kernels now, not in the first timed launch
+        if ((st = (int)bf_warm_module_mfma()) != 0) break;
         const size_t tb = (size_t)c->n_pairs * sizeof(dcs_delay_vals);
         if ((st = (int)hipMalloc((void **)&c->d_table[0], tb)) != 0) break;
         if ((st = (int)hipMalloc((void **)&c->d_table[1], tb)) != 0) break;

@@ -155,6 +155,7 @@ struct bf_bacc_args {
     dcs_bf_consts k;
 };
 hipError_t bf_launch_beamform_acc(const bf_bacc_args &a, hipStream_t stream);
+hipError_t bf_warm_module_mfma();
 
 // One coefficient per lane, one time step (reference kernel a1's shape).
 struct bf_naive_args {
