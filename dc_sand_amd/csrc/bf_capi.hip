@@ -1144,7 +1144,7 @@ int dcs_bf_autotune(dcs_bf_context *c, int bitwidth, void *d_out, size_t out_byt
     static const int k32[][3] = {{1, 6, -1}, {1, 7, -1}, {1, 8, -1}, {1, 9, -1}, {1, 10, -1}, {1, 11, -1}, {1, 12, -1}, {1, 13, -1},
                                  {1, 14, -1}, {1, 16, -1}, {1, 7, 7}, {1, 8, 7}, {1, 9, 7}, {1, 10, 7}, {1, 11, 7}, {1, 12, 7},
                                  {1, 13, 7}, {1, 7, 6}, {1, 8, 6}, {1, 9, 6}, {1, 10, 6}, {1, 11, 6}, {1, 12, 6}, {1, 13, 6},
-                                 {1, 14, 6}, {1, 8, 5}, {1, 14, 5}, {1, 16, 5}, {2, 6, -1}, {2, 8, -1}};
+                                 {1, 14, 6}, {1, 8, 5}, {1, 9, 5}, {1, 10, 5}, {1, 11, 5}, {1, 12, 5}, {1, 14, 5}, {1, 16, 5}, {2, 6, -1}, {2, 8, -1}};
     static const int k16[][3] = {{1, 16, -1}, {1, 24, -1}, {1, 32, -1}, {1, 48, -1}, {1, 64, -1}, {1, 96, -1}, {1, 128, -1},
                                  {1, 192, -1}, {1, 256, -1}, {1, 24, 6}, {1, 32, 6}, {1, 48, 6}, {1, 64, 6}, {1, 32, 7},
                                  {1, 64, 7}, {1, 128, 7}, {2, 32, -1}, {2, 64, -1}};
