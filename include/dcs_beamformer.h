@@ -267,7 +267,8 @@ int dcs_bf_beamform_accumulated_dt(dcs_bf_context *ctx, float dt_coeff, uint32_t
  *   form 2 "rows":  the terms table for any number of time steps, then short waves
  *           (waves_per_block adjacent 1-KiB tiles x rows_per_wave channel rows)
  *           stream the tensor in address order.
- * MULTIPLE_CHANNELS always uses the tiled form (the reference's per-time-step shape). */
+ * MULTIPLE_CHANNELS always uses the tiled form (the reference's per-time-step shape); from 8 time steps on its
+ * launches are spread over four internal streams between a fork and a join on the caller's stream. */
 struct dcs_bf_tuning {
     int32_t form;            /* 0 default (tiled; terms table for large launches), 1 tiled with per-workgroup terms,
                               * 2 rows, 3 tiled with the terms table */

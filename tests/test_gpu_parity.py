@@ -1066,8 +1066,8 @@ def test_seeded_fuzz_of_shapes_slabs_time_ranges_and_geometries(gpu, oracle):
         buf.free()
 
 
-@pytest.mark.parametrize("nt", [1, 256])
-def test_generate_under_stream_capture(gpu, oracle, nt):
+@pytest.mark.parametrize("nt,kernel", [(1, 2), (256, 2), (16, 1), (3, 1), (16, 0)])
+def test_generate_under_stream_capture(gpu, oracle, nt, kernel):
     """include/dcs_beamformer.h: "all device work is enqueued on the caller's stream so the calls can be
     captured in a hipGraph".  dcs_bf_generate under hipStreamBeginCapture / EndCapture (up to 256 time steps:
     their fDeltaTime values are kernel arguments; longer launches stage a table through pinned memory and
@@ -1095,7 +1095,7 @@ def test_generate_under_stream_capture(gpu, oracle, nt):
     buf = gpu.mem_alloc(nbytes)
     s = gpu.Stream()
     assert hip.hipStreamBeginCapture(V(s.handle), 0) == 0  # hipStreamCaptureModeGlobal
-    g.generate(buf, nbytes, t0=7, nt=nt, stream=s.handle)
+    g.generate(buf, nbytes, t0=7, nt=nt, stream=s.handle, kernel=kernel)  # (kernel 1 from 8 time steps on: a fork and a join over side streams)
     graph = V()
     assert hip.hipStreamEndCapture(V(s.handle), ctypes.byref(graph)) == 0 and graph.value
     ex = V()
