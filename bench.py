@@ -5,11 +5,20 @@
 
 One "step" = one pass of the hot path over one batch: generate one time step of
 the 64 ant x 1024 beam x 32768 chan coefficient tensor (16 GiB, fp32 complex)
-per GPU from a delay table already resident in HBM.  With N > 1 (launched by
-``python -m torch.distributed.run``, one rank per GPU) the BEAM axis is sharded:
+per GPU from a delay table already resident in HBM.  With N > 1 (one rank per GPU) the BEAM axis is sharded:
 the global table holds 1024*N beams, rank 0 broadcasts it over RCCL every step
 (issued asynchronously one step ahead, double-buffered, so it overlaps the generation), each rank gathers its 1024-beam
 slice and generates its own column slab -- no other collective (weak scaling).
+
+LAUNCH CONTRACT.  ``--gpus N`` ALWAYS means N ranks, one per GPU:
+  * under a launcher (``python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N``: RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_* in the environment) this process IS one of the N ranks; WORLD_SIZE != N is an error;
+  * without one (plain ``python bench.py --gpus N``, N > 1) this process starts the N ranks itself -- fresh child
+    processes, created BEFORE anything here touches torch or the GPU, rendezvous on 127.0.0.1 -- relays rank 0's one
+    JSON line and exits non-zero, printing NO line, if any rank fails (fewer than N GPUs, a rank dying, a timeout).
+  It never prints an ``n_gpus: 1`` line for a ``--gpus 8`` request.
+``--config cfg3`` (default) is BASELINE configs[2], the metric's config; ``--config cfg4`` is configs[3]'s per-GPU
+share (256 ant x 4096/8 = 512 beams per GPU x 32768 chan); the name is in ``config.workload``.
 
 Rank 0 prints ONE JSON line.  ``roofline`` prices the dominant kernel against
 the 8 TB/s HBM peak with its ALGORITHMIC bytes (8 B per coefficient written);
@@ -38,7 +47,11 @@ sys.path.insert(0, str(ROOT))
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s (spec)
-ANT, BEAMS_PER_GPU, CHAN = 64, 1024, 32768
+CONFIGS = {  # SURVEY.md numbering (1-based): cfg3 = BASELINE.json configs[2], cfg4 = configs[3]
+    "cfg3": dict(ant=64, beams_per_gpu=1024, chan=32768, name="BASELINE configs[2]: 64 ant x 1024 beam x 32768 chan on one GPU"),
+    "cfg4": dict(ant=256, beams_per_gpu=512, chan=32768, name="BASELINE configs[3]: 256 ant x 4096 beam x 32768 chan beam-sharded over 8 GPUs "
+                                                              "(512 beams per GPU)"),
+}
 
 
 def parse():
@@ -46,9 +59,19 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--ant", type=int, default=ANT)
-    ap.add_argument("--beams-per-gpu", type=int, default=BEAMS_PER_GPU)
-    ap.add_argument("--chan", type=int, default=CHAN)
+    ap.add_argument("--config", default="cfg3", choices=sorted(CONFIGS),
+                    help="named workload (SURVEY.md numbering): cfg3 = BASELINE configs[2], 64 ant x 1024 beams per GPU x 32768 chan "
+                         "(the metric's config); cfg4 = BASELINE configs[3]'s per-GPU share, 256 ant x 512 beams per GPU (4096 over "
+                         "8 GPUs) x 32768 chan.  --ant / --beams-per-gpu / --chan override single dimensions")
+    ap.add_argument("--ant", type=int, default=None)
+    ap.add_argument("--beams-per-gpu", type=int, default=None)
+    ap.add_argument("--chan", type=int, default=None)
+    ap.add_argument("--streaming", action="store_true",
+                    help="each step is a hipGraph replay (BASELINE configs[4]'s launch) whose delay table comes from the "
+                         "broadcast's DEVICE buffer through a gather node of the graph (dcs_bf_stream_tick_dt_from_global): "
+                         "configs[3] and configs[4] composed; model time advances 200 us per step")
+    ap.add_argument("--launch-timeout", type=float, default=1500.0,
+                    help="--gpus N > 1 without a launcher: seconds the parent waits for its N rank processes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the fp16 / fused-beamformer side measurements (N = 1)")
     ap.add_argument("--per-step-events", action="store_true",
@@ -69,7 +92,73 @@ def parse():
     ap.add_argument("--force-collective", action="store_true",
                     help="rehearsal on one GPU: run the N > 1 control flow (process group, per-step broadcast on the side "
                          "stream, double-buffered table, slice gather) with a world of ONE rank over RCCL")
-    return ap.parse_args()
+    args = ap.parse_args()
+    named = CONFIGS[args.config]
+    shape_overridden = any(v is not None for v in (args.ant, args.beams_per_gpu, args.chan))
+    args.ant = named["ant"] if args.ant is None else args.ant
+    args.beams_per_gpu = named["beams_per_gpu"] if args.beams_per_gpu is None else args.beams_per_gpu
+    args.chan = named["chan"] if args.chan is None else args.chan
+    args.config_name = args.config + (" (shape overridden)" if shape_overridden else "")
+    return args
+
+
+def launch_ranks(args) -> int:
+    """``--gpus N`` (N > 1) without a launcher: start the N ranks as fresh child processes of this command line --
+    the parent has made no torch / HIP call -- with the environment a launcher would give them, relay rank 0's one
+    JSON line, and report failure (non-zero, no line) if any rank does not finish cleanly."""
+    import socket
+    import subprocess
+    import threading
+
+    N = args.gpus
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(N):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(N), LOCAL_WORLD_SIZE=str(N), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve()), *sys.argv[1:]], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0 = []
+    reader = threading.Thread(target=lambda: out0.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    deadline = time.monotonic() + args.launch_timeout
+    failed = None
+    while failed is None:
+        codes = [p.poll() for p in procs]
+        bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+        if bad:
+            failed = f"rank {bad[0][0]} exited with status {bad[0][1]}"
+        elif all(c == 0 for c in codes):
+            break
+        elif time.monotonic() > deadline:
+            failed = f"the ranks did not finish within {args.launch_timeout:.0f} s"
+        else:
+            time.sleep(0.05)
+    if failed is not None:
+        for p in procs:  # exactly the processes started here
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                p.kill()
+        print(f"bench.py --gpus {N}: {failed}; no result line is printed (a run of fewer ranks is not a run of {N})", file=sys.stderr)
+        return 1
+    reader.join(timeout=10)
+    lines = [l for l in (out0[0] if out0 else b"").decode().splitlines() if l.strip()]
+    if len(lines) != 1:
+        print(f"bench.py --gpus {N}: rank 0 printed {len(lines)} lines instead of one", file=sys.stderr)
+        return 1
+    d = json.loads(lines[0])
+    if d.get("n_gpus") != N or len(d.get("per_rank", [])) != N:
+        print(f"bench.py --gpus {N}: rank 0's line is not a {N}-rank result: n_gpus={d.get('n_gpus')}", file=sys.stderr)
+        return 1
+    sys.stdout.write(lines[0] + "\n")
+    sys.stdout.flush()
+    return 0
 
 
 def cpu_baseline(bp, table, seconds: float) -> dict:
@@ -129,16 +218,20 @@ def cpu_baseline(bp, table, seconds: float) -> dict:
     return out
 
 
-def extras(gen, bp, out, out_bytes, sh, device, sustain_seconds: float) -> dict:
+def extras(gen, bp, out, out_bytes, sh, device, sustain_seconds: float, samples: list) -> dict:
     """Side measurements after the timed region (N = 1), same HIP-event method:
     * ``sustained``: >= 5 s of back-to-back steps of the headline workload at the geometry the headline ran with
       (the chip's write rate sags ~1-3 % over the first seconds of load; a real-time generator lives there);
     * ``streaming_cfg5``: BASELINE configs[4] -- hipGraph replay, one time step per tick, model time advancing
       200 us per tick (dcs_bf_stream_tick_dt): the full tensor's update period (it cannot meet 200 us: 16 GiB
-      need >= 2.15 ms at the 8 TB/s peak) and the largest channel slab whose period stays <= 200 us;
+      need >= 2.15 ms at the 8 TB/s peak) and the largest channel slab whose period stays <= 200 us; both also with a NEW
+      DELAY TABLE ON EVERY TICK, from host memory (pinned ring + H2D copy) and from device memory (gather node in the graph);
     * ``fp16_output``: the b16 output mode (SURVEY 8 f2), exact-RNE form and the opt-in b16 arithmetic form;
     * ``fused_generate_and_beamform`` (f1) on a 64 x 64 x 4096 x 64 problem;
-    * ``beamform_accumulated``: the coefficient-reuse beamformer (256 samples per coefficient) at 16 and 256 beams."""
+    * ``beamform_accumulated``: the coefficient-reuse beamformer (256 samples per coefficient) at 16 and 256 beams, and the
+      K-split form at 256 antennas.
+    Nothing here touches oracle/: a few rows of each item's LAST output are copied to the host into ``samples`` and
+    compared with the oracle later, in the cpu_baseline leg (``cpu_baseline.extras_vs_oracle``)."""
     from dc_sand_amd import BeamformerParameters
     from dc_sand_amd.generator import SteeringCoefficientGenerator, simulate_input
 
@@ -155,6 +248,14 @@ def extras(gen, bp, out, out_bytes, sh, device, sustain_seconds: float) -> dict:
 
     res = {}
     n_coeff = bp.coeffs_per_time_step()
+    row_bytes = bp.n_pairs * 8
+
+    def sample_rows(rows, row_b, dtype):
+        host = np.empty((len(rows), bp.NR_STATIONS, bp.NR_BEAMS, 2), dtype=dtype)
+        device.stream_synchronize(sh)
+        for i, r in enumerate(rows):
+            device.memcpy_dtoh(host[i], out.data_ptr() + r * row_b)
+        return host
 
     # -- sustained: batches of 50 launches, the host one batch ahead of the device; per-second rates kept
     batch, k, total_ms, launches, per_sec = 50, 0, 0.0, 0, []
@@ -186,24 +287,48 @@ def extras(gen, bp, out, out_bytes, sh, device, sustain_seconds: float) -> dict:
                         "per_second": per_sec, "note": "back-to-back steps of the headline workload, same kernel and launch geometry"}
 
     # -- BASELINE configs[4]: streaming at a 200 us cadence
-    def tick_period_us(nc, ticks=150, warm=15):
+    tab = [np.ascontiguousarray(simulate_input(bp)), np.ascontiguousarray(simulate_input(bp))]
+    tab[1]["fPhase_rad"] += np.float32(0.25)  # a second delay model, so that a table update is visible in the output
+    d_tab = [device.mem_alloc(t.nbytes) for t in tab]
+    for d, t in zip(d_tab, tab):
+        device.memcpy_htod(d, t)
+
+    def tick_period_us(nc, ticks=150, warm=15, table=None):
+        """table: None = the table stays; "host" / "device" = a new table with EVERY tick, from host / device memory."""
         nbytes = nc * bp.n_pairs * 8
+        gen.upload_delays(tab[0], stream=sh)  # every run starts from the headline's table
         st = gen.stream_begin(out.data_ptr(), nbytes, 0, nc, sh)
+
+        def tick(i):
+            if table == "host":
+                st.tick_dt(i * 200e-6, tab[i % 2])
+            elif table == "device":
+                st.tick_dt_from_global(i * 200e-6, d_tab[i % 2])
+            else:
+                st.tick_dt(i * 200e-6)
+
         for i in range(warm):
-            st.tick_dt(i * 200e-6)
+            tick(i)
         device.stream_synchronize(sh)
         e0, e1 = device.Event().record(sh), device.Event()
         t0 = time.perf_counter()
         for i in range(ticks):
-            st.tick_dt((warm + i) * 200e-6)
+            tick(warm + i)
         e1.record(sh)
         e1.synchronize()
         wall = (time.perf_counter() - t0) / ticks * 1e6
         dev = e1.elapsed_ms_since(e0) / ticks * 1e3
+        last = warm + ticks - 1
+        rows = sorted({0, nc // 2, nc - 1})
+        samples.append({"item": f"streaming_cfg5: {nc} channels, table {'unchanged' if table is None else 'new every tick from ' + table + ' memory'}",
+                        "kind": "generate", "dt": float(np.float32(last * 200e-6)), "rows": rows,
+                        "table": tab[last % 2] if table else None, "data": sample_rows(rows, row_bytes, np.float32)})
         st.end()
         return max(dev, wall), nbytes
 
     full_us, full_bytes = tick_period_us(bp.NR_CHANNELS, ticks=60, warm=6)
+    full_host_us, _ = tick_period_us(bp.NR_CHANNELS, ticks=60, warm=6, table="host")
+    full_dev_us, _ = tick_period_us(bp.NR_CHANNELS, ticks=60, warm=6, table="device")
     best = None
     for nc in (1536, 2048, 2304, 2432, 2560, 2688, 2816):
         if nc > bp.NR_CHANNELS:
@@ -211,9 +336,23 @@ def extras(gen, bp, out, out_bytes, sh, device, sustain_seconds: float) -> dict:
         us, nb = tick_period_us(nc)
         if us <= 200.0:
             best = {"channels": nc, "bytes_per_tick": nb, "period_us": us, "Mcoeff_per_tick": nc * bp.n_pairs / 1e6, "TBps": nb / us / 1e6}
+    every = None
+    if best is not None:  # the same slab with a new table on every tick
+        h_us, _ = tick_period_us(best["channels"], table="host")
+        d_us, _ = tick_period_us(best["channels"], table="device")
+        every = {"channels": best["channels"], "host_table_period_us": h_us, "device_table_period_us": d_us,
+                 "table_bytes": int(tab[0].nbytes)}
     res["streaming_cfg5"] = {"cadence_target_us": 200.0, "model_time_step_us": 200.0, "launch": "hipGraph replay, dcs_bf_stream_tick_dt",
                              "full_tensor_period_us": full_us, "full_tensor_TBps": full_bytes / full_us / 1e6,
-                             "meets_200us_full_tensor": bool(full_us <= 200.0), "largest_slab_at_200us": best}
+                             "meets_200us_full_tensor": bool(full_us <= 200.0), "largest_slab_at_200us": best,
+                             "new_table_every_tick": {"full_tensor_host_table_period_us": full_host_us,
+                                                      "full_tensor_device_table_period_us": full_dev_us, "slab_at_200us": every,
+                                                      "note": "host: memcpy into a ring of 4 pinned buffers + H2D copy in front of the "
+                                                              "replay (dcs_bf_stream_tick_dt); device: gather node inside the replayed "
+                                                              "graph (dcs_bf_stream_tick_dt_from_global), no host staging"}}
+    for d in d_tab:
+        d.free()
+    gen.upload_delays(tab[0], stream=sh)  # back to the headline's table
 
     # -- fp16 output, both arithmetic forms (library default geometry for each)
     nb16 = gen.output_bytes(0, 1)
@@ -223,31 +362,54 @@ def extras(gen, bp, out, out_bytes, sh, device, sustain_seconds: float) -> dict:
         res[key] = {"value": n_coeff / ms / 1e6, "unit": "Gcoeff/s", "ms": ms, "hbm_GBps": nb16 / ms / 1e6,
                     "frac_of_hbm_peak": nb16 / ms / 1e6 / HBM_PEAK_GBPS, "math_mode": mode,
                     "bound": "4 B written per coefficient: fp32 VALU issue (exact-RNE form) / HBM write pattern (b16 form)"}
+        rows = sorted({0, bp.NR_CHANNELS // 2, bp.NR_CHANNELS - 1})
+        samples.append({"item": key, "kind": "generate_f16", "t": 1, "rows": rows, "table": None,
+                        "data": sample_rows(rows, row_bytes // 2, np.float16)})
     gen.set_tuning()
+
+    def antenna_pattern(nbytes):
+        """Device buffer of pseudo-random int8 samples: a 32 MiB seeded block repeated (D2D copies)."""
+        blk = min(nbytes, 32 << 20)
+        host = np.random.default_rng(0xA17).integers(-128, 128, size=blk, dtype=np.int8)
+        d = device.mem_alloc(nbytes)
+        device.memcpy_htod(d, host, stream=sh)
+        off = blk
+        while off < nbytes:
+            n = min(off, nbytes - off)  # doubling
+            device.memcpy_dtod(int(d) + off, d, n, sh)
+            off += n
+        device.stream_synchronize(sh)
+        return d, host
+
     A, B, C, nt = 64, 64, 4096, 64
     fp = BeamformerParameters(NR_CHANNELS=C, NR_STATIONS=A, NR_BEAMS=B, NR_SAMPLES_PER_CHANNEL=nt)
     g = SteeringCoefficientGenerator(fp)
     g.upload_delays(simulate_input(fp), stream=sh)
     ant_bytes, beam_bytes = A * C * nt * 2, B * C * nt * 8
-    d_ant, d_beams = device.mem_alloc(ant_bytes), device.mem_alloc(beam_bytes)
-    device.memset(d_ant, 3, ant_bytes, stream=sh)
+    d_ant, ant_host = antenna_pattern(ant_bytes)
+    d_beams = device.mem_alloc(beam_bytes)
     ms = timed(lambda: g.generate_and_beamform(d_ant, ant_bytes, d_beams, beam_bytes, 0, nt, stream=sh))
     res["fused_generate_and_beamform"] = {"value": A * B * C * nt / ms / 1e6, "unit": "G coefficient-products/s", "ms": ms,
                                           "shape": f"{A}ant x {B}beam x {C}chan x {nt}samples", "bound": "fp32 VALU (no coefficient reaches HBM)"}
     device.stream_synchronize(sh)
+    nchk = 2
+    got = np.empty((nchk, nt // 16, B, 16, 2), dtype=np.float32)
+    device.memcpy_dtoh(got, d_beams)
+    samples.append({"item": "fused_generate_and_beamform", "kind": "beamform", "shape": (A, B, C, nt), "nc": nchk,
+                    "ant": ant_host[: nchk * nt * A * 2].copy(), "data": got})
     g.close()
     d_ant.free()
     d_beams.free()
     # -- the same beamformer with the coefficients of ONE time reused for 256 samples (ACCUMULATIONS_BEFORE_NEW_COEFFS,
     #    BeamformerParameters.h:17): exact fixed-point contraction on the int8 matrix pipe; roofline = HBM
     res["beamform_accumulated"] = []
-    for (A, B, C, nt) in ((64, 16, 32768, 256), (64, 256, 4096, 256)):
+    for (A, B, C, nt) in ((64, 16, 32768, 256), (64, 256, 4096, 256), (256, 64, 4096, 256)):
         fp = BeamformerParameters(NR_CHANNELS=C, NR_STATIONS=A, NR_BEAMS=B, NR_SAMPLES_PER_CHANNEL=nt)
         g = SteeringCoefficientGenerator(fp)
         g.upload_delays(simulate_input(fp), stream=sh)
         ant_bytes, beam_bytes = A * C * nt * 2, B * C * nt * 8
-        d_ant, d_beams = device.mem_alloc(ant_bytes), device.mem_alloc(beam_bytes)
-        device.memset(d_ant, 3, ant_bytes, stream=sh)
+        d_ant, ant_host = antenna_pattern(ant_bytes)
+        d_beams = device.mem_alloc(beam_bytes)
         ms = timed(lambda: g.beamform_accumulated(d_ant, ant_bytes, d_beams, beam_bytes, nt, t_coeff=1, stream=sh), n=40, warm=20)
         res["beamform_accumulated"].append({
             "value": A * B * C * nt / ms / 1e9, "unit": "T coefficient-products/s", "ms": ms, "shape": f"{A}ant x {B}beam x {C}chan x {nt}samples",
@@ -255,10 +417,61 @@ def extras(gen, bp, out, out_bytes, sh, device, sustain_seconds: float) -> dict:
             "frac_of_hbm_peak": (ant_bytes + beam_bytes) / ms / 1e6 / HBM_PEAK_GBPS,
             "bound": "HBM (2 B per antenna and sample in, 8 B per beam and sample out); v_mfma_i32_16x16x64_i8 on 24-bit fixed-point coefficients"})
         device.stream_synchronize(sh)
+        nchk = 2
+        got = np.empty((nchk, nt // 16, B, 16, 2), dtype=np.float32)
+        device.memcpy_dtoh(got, d_beams)
+        samples.append({"item": f"beamform_accumulated {A}x{B}x{C}x{nt}", "kind": "beamform_accumulated", "shape": (A, B, C, nt), "nc": nchk,
+                        "ant": ant_host[: nchk * nt * A * 2].copy(), "data": got})
         g.close()
         d_ant.free()
         d_beams.free()
     return res
+
+
+def check_extras_against_oracle(bp, table, samples: list) -> list:
+    """The rows ``extras`` copied back, against the oracle (part of the cpu_baseline leg: the only place where bench.py
+    touches oracle/).  fp32 generator rows: ULP distance (bar 1); fp16 rows: binary16 ulps from RN-even(oracle) (bar 1);
+    beamformers: largest |difference| against the verifier's loop over the first channels, bar 2e-5 / 4e-5 x antennas
+    (tests/test_gpu_parity.py, include/dcs_beamformer.h; the reference's own tolerance is 1e-1)."""
+    from dc_sand_amd import BeamformerParameters
+    from dc_sand_amd.generator import delta_times, simulate_input
+    from oracle import bf_oracle as orc
+
+    op = orc.params_from(bp)
+    out = []
+    for s in samples:
+        if s["kind"] in ("generate", "generate_f16"):
+            tbl = table if s["table"] is None else s["table"]
+            dt = [np.float32(s["dt"])] if "dt" in s else delta_times(bp, s["t"], 1)
+            worst = 0
+            for i, r in enumerate(s["rows"]):
+                exp = orc.generate_dt(op, tbl, dt, r, 1)[0, 0]
+                if s["kind"] == "generate":
+                    worst = max(worst, orc.max_ulp(s["data"][i], exp, 1)[0])
+                else:
+                    have = s["data"][i].view(np.uint16).astype(np.int32)
+                    want = exp.astype(np.float16).view(np.uint16).astype(np.int32)
+                    o = lambda u: np.where(u & 0x8000, -(u & 0x7FFF), u & 0x7FFF)  # noqa: E731
+                    worst = max(worst, int(np.abs(o(have) - o(want)).max()))
+            out.append({"item": s["item"], "rows_checked": len(s["rows"]), "max_ulp": int(worst), "bar": 1, "ok": bool(worst <= 1),
+                        "unit": "fp32 ULP" if s["kind"] == "generate" else "binary16 ulp of RN-even(oracle)"})
+        else:
+            A, B, C, nt = s["shape"]
+            fp = BeamformerParameters(NR_CHANNELS=C, NR_STATIONS=A, NR_BEAMS=B, NR_SAMPLES_PER_CHANNEL=nt)
+            fop = orc.params_from(fp)
+            ftab = simulate_input(fp)
+            ant = s["ant"].reshape(s["nc"], nt // 16, A, 16, 2)
+            if s["kind"] == "beamform":
+                exp = orc.beamform_slab(fop, ftab, nt, 0, s["nc"], ant)
+            else:
+                exp = orc.beamform_accumulated_slab(fop, ftab, delta_times(fp, 1, 1)[0], nt, 0, s["nc"], ant)
+            err = float(np.abs(s["data"].astype(np.float64) - exp.astype(np.float64)).max())
+            # per-sample kernel: the verifier's own summation order, <= 1 ULP per coefficient (tests: 2e-5 x antennas);
+            # coefficient-reuse kernel: include/dcs_beamformer.h's worst-case bound, 4e-5 x antennas
+            bar = (2e-5 if s["kind"] == "beamform" else 4e-5) * A + 1e-6
+            out.append({"item": s["item"], "channels_checked": s["nc"], "max_abs_err": err, "bar": bar, "ok": bool(err <= bar),
+                        "largest_expected_magnitude": float(np.abs(exp).max())})
+    return out
 
 
 def pmc_traffic(bytes_algo: int):
@@ -280,6 +493,11 @@ def pmc_traffic(bytes_algo: int):
 
 def main():
     args = parse()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        # no launcher: this process only starts the ranks and relays rank 0's line (no torch, no HIP call here)
+        raise SystemExit(launch_ranks(args))
     # stdout carries exactly ONE line, the JSON: anything libraries print there on the way
     # (RCCL's version banner, for one) goes to stderr instead
     sys.stdout.flush()
@@ -288,9 +506,10 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    N = max(world, 1)
+    # the launch contract (module docstring): --gpus N is N ranks, or no result at all
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: one rank per GPU, N ranks for --gpus N")
+    N = args.gpus
 
     # the host driver of this pool only supports dmabuf IPC; without this RCCL's cross-process buffer
     # registration fails (hipIpcGetMemHandle: invalid argument).  Already exported on the boxes; kept here
@@ -299,10 +518,13 @@ def main():
 
     import torch
 
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
     if args.shared_device:
         local_rank = 0
+    if local_rank >= torch.cuda.device_count():  # (counting devices does not initialise the GPU)
+        raise SystemExit(f"bench.py: rank {rank} needs GPU {local_rank}, but this machine shows {torch.cuda.device_count()} HIP device(s) "
+                         "(no CPU fallback; --shared-device is a rehearsal flag, never a result)")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dist = None
     use_dist = N > 1 or args.force_collective
@@ -364,10 +586,18 @@ def main():
         if use_dist:
             works[k % 2] = dist.broadcast(tbl[k % 2], src=0, async_op=True)
 
+    coeff_stream = None  # --streaming: one hipGraph over the whole tensor, replayed per step
+
     def step(k: int):
         b = k % 2
         if use_dist:
             works[b].wait()  # the main stream waits for the broadcast; the host does not block
+        if coeff_stream is not None:
+            # BASELINE configs[3] + configs[4]: the broadcast's device buffer feeds the replayed graph directly (gather node,
+            # then pre-pass + generator); model time advances 200 us per step
+            coeff_stream.tick_dt_from_global(k * 200e-6, tbl[b].data_ptr(), B_total, beam_off)
+            prefetch(k + 1)
+            return
         gen.set_delays_from_global(tbl[b].data_ptr(), B_total, beam_off, stream=sh)
         prefetch(k + 1)
         gen.generate(out.data_ptr(), out_bytes, t0=1 + (k % 255), nt=1, stream=sh)
@@ -404,6 +634,8 @@ def main():
     for _ in range(max(4, min(400, int(40.0 / max(two.elapsed_ms_since(one), 1e-3))))):
         gen.generate(out.data_ptr(), out_bytes, t0=1, nt=1, stream=sh)
 
+    if args.streaming:
+        coeff_stream = gen.stream_begin(out.data_ptr(), out_bytes, 0, args.chan, sh)
     prefetch(0)
     for k in range(args.warmup):
         step(k)
@@ -465,16 +697,18 @@ def main():
         from oracle import bf_oracle as orc
 
         k_last = args.warmup + args.steps - 1
-        t_last = 1 + (k_last % 255)
-        nchk = 4
+        from dc_sand_amd.generator import delta_times
+
+        dt_last = [np.float32(k_last * 200e-6)] if args.streaming else delta_times(bp, 1 + (k_last % 255), 1)
+        nchk = min(4, args.chan)
         host = np.empty((nchk, args.ant, args.beams_per_gpu, 2), dtype=np.float32)
         device.memcpy_dtoh(host, out.data_ptr(), nbytes=host.nbytes)
         full = simulate_input(bp_global).reshape(args.ant, B_total)
         local = np.ascontiguousarray(full[:, beam_off:beam_off + args.beams_per_gpu]).ravel()
-        exp = orc.generate(orc.params_from(bp), local, t_last, 1, 0, nchk)
+        exp = orc.generate_dt(orc.params_from(bp), local, dt_last, 0, nchk)
         mx, n_over, _ = orc.max_ulp(host, exp, 1)
         with orc.trig_reading(orc.FLOAT_LIBM):  # the verifier's other reading (oracle/bf_oracle.c)
-            mx_f, _, _ = orc.max_ulp(host, orc.generate(orc.params_from(bp), local, t_last, 1, 0, nchk), 1)
+            mx_f, _, _ = orc.max_ulp(host, orc.generate_dt(orc.params_from(bp), local, dt_last, 0, nchk), 1)
         return int(mx), int(n_over), int(mx_f)
 
     if args.check_all_ranks:
@@ -507,11 +741,14 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"{args.ant}ant x {B_total}beam x {args.chan}chan, 1 time step per step, "
+                "workload": f"{args.config_name}: {args.ant}ant x {B_total}beam x {args.chan}chan, 1 time step per step, "
                             f"beam-sharded {args.beams_per_gpu} beams/GPU" + (f", {args.backend} bcast of the delay table each step" if use_dist else ""),
+                "named_config": CONFIGS[args.config]["name"] + (" -- shape overridden on the command line" if "overridden" in args.config_name else ""),
                 "coeffs_per_step": coeffs_per_gpu_step * N,
                 "output_bytes_per_gpu_step": out_bytes,
-                "kernel": "MULTIPLE_CHANNELS_AND_TIMESTAMPS (tiled form; launches of >= 2 GiB read the pairs' terms from a pre-pass table)",
+                "kernel": ("MULTIPLE_CHANNELS_AND_TIMESTAMPS (tiled form; launches of >= 2 GiB read the pairs' terms from a pre-pass table)"
+                           + ("; each step a hipGraph replay with the table gathered in-graph from the broadcast's device buffer "
+                              "(dcs_bf_stream_tick_dt_from_global)" if args.streaming else "")),
                 "launch_geometry": ({k: tuning[k] for k in ("tiles_per_block", "chan_per_block", "nontemporal", "wg_per_cu")} if tuning
                                     else "library defaults"),
                 "collective": ("none" if not use_dist else ("RCCL broadcast" if args.backend == "nccl" else "gloo broadcast (REHEARSAL, not a result)")),
@@ -535,10 +772,15 @@ def main():
         check = None
         if N == 1 and not args.no_cpu_baseline:
             check = spot_check()  # before anything else rewrites the output buffer
+        samples = []
         if N == 1 and not args.no_extras:
-            result["also_measured"] = extras(gen, bp, out, out_bytes, sh, device, args.sustain_seconds)
+            result["also_measured"] = extras(gen, bp, out, out_bytes, sh, device, args.sustain_seconds, samples)
         if N == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(bp, np.ascontiguousarray(table_host), args.cpu_seconds)
+            if samples:
+                chk = check_extras_against_oracle(bp, np.ascontiguousarray(table_host), samples)
+                result["cpu_baseline"]["extras_vs_oracle"] = chk
+                assert all(c["ok"] for c in chk), [c for c in chk if not c["ok"]]
             result["cpu_baseline"]["gpu_vs_oracle_spot_check"] = {"max_ulp": check[0], "over_1ulp": check[1],
                                                                   "max_ulp_float_libm_reading": check[2],
                                                                   "sample": "first 4 channels of the last timed step"}
@@ -546,6 +788,8 @@ def main():
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(result) + "\n").encode())
 
+    if coeff_stream is not None:
+        coeff_stream.end()
     gen.close()
     if use_dist:
         for w in works:  # the last prefetched broadcast has no consumer

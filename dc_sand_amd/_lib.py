@@ -100,8 +100,13 @@ SIGNATURES = [
     ("dcs_bf_stream_tick", c_int, [_VP, c_uint64, _VP]),
     ("dcs_bf_stream_tick_dt", c_int, [_VP, c_float, _VP]),
     ("dcs_bf_stream_tick_at", c_int, [_VP, POINTER(Timespec), POINTER(Timespec), _VP]),
+    ("dcs_bf_stream_tick_from_global", c_int, [_VP, c_uint64, _VP, c_uint32, c_uint32]),
+    ("dcs_bf_stream_tick_dt_from_global", c_int, [_VP, c_float, _VP, c_uint32, c_uint32]),
+    ("dcs_bf_stream_tick_at_from_global", c_int, [_VP, POINTER(Timespec), POINTER(Timespec), _VP, c_uint32, c_uint32]),
     ("dcs_bf_stream_end", c_int, [_VP]),
 ]
+
+ABI_VERSION = 3  # include/dcs_beamformer.h: DCS_BF_ABI_VERSION
 
 _LIB = None
 
@@ -119,6 +124,9 @@ def _lib() -> ctypes.CDLL:
             fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
             fn.restype = restype
             fn.argtypes = argtypes
+        if lib.dcs_abi_version() != ABI_VERSION:  # a stale build: struct dcs_bf_tuning changed between 2 and 3
+            raise ImportError(f"{LIB_PATH} has ABI version {lib.dcs_abi_version()}, this package binds version {ABI_VERSION}: "
+                              "rebuild it with `python -m dc_sand_amd.build --force`")
         _LIB = lib
     return _LIB
 

@@ -472,10 +472,13 @@ bf_beamform_i8_kernel(const bf_bacc_args a)
         return reinterpret_cast<floatx4 *>(base + ((second ? (blkB - blkA) * tpr * out_blk : 0u) + bb * 128u + m * 16u + 512u * r));
     };
     auto store = [&](floatx4 *dst, const floatx4 o) {
-        if (a.plain_stores)
+#ifdef DCS_PROBES
+        if (a.plain_stores) { // probes build only: the A/B of profiles/r02_fused.md
             *dst = o;
-        else
-            __builtin_nontemporal_store(o, dst); // written once, read by another kernel: do not keep it in L2
+            return;
+        }
+#endif
+        __builtin_nontemporal_store(o, dst); // written once, read by another kernel: do not keep it in L2
     };
     // scale and store: lane l, register r = beam bw + (l >> 4) + 4 r, samples 2 m, 2 m + 1
     auto finish = [&](auto whole, uint32_t blk, const floatx4 (&f)[4]) {
@@ -661,8 +664,8 @@ hipError_t bf_launch_beamform_acc(const bf_bacc_args &a_in, hipStream_t stream)
     // generated once per workgroup; but a launch of only a few thousand long-lived workgroups ends with most of the
     // chip idle behind the last ones), fewer while that leaves the chip under 4096 workgroups
     const uint32_t tpr = split ? 1u : 4u / (uint32_t)nbt; // (K-split: every wave takes every block)
-    const bool staged_form = !chain && a.A <= 64u && !a.unstaged; // at most 16 blocks (32 KiB of LDS) per workgroup
-    const uint32_t max_rounds = a.max_rounds ? a.max_rounds : (chain ? 16u : (staged_form || split ? 16u / tpr : 32u));
+    const bool staged_form = !chain && a.A <= 64u && !BACC_KNOB(a, unstaged); // at most 16 blocks (32 KiB of LDS) per workgroup
+    const uint32_t max_rounds = BACC_KNOB(a, max_rounds) ? BACC_KNOB(a, max_rounds) : (chain ? 16u : (staged_form || split ? 16u / tpr : 32u));
     uint32_t tiles = (a.nT16 + tpr - 1u) / tpr * tpr;
     if (tiles > max_rounds * tpr) { // several workgroups per (channel, beam group): equal shares (17 blocks are 9 + 8, not 16 + 1)
         const uint32_t parts = (a.nT16 + max_rounds * tpr - 1u) / (max_rounds * tpr);
@@ -684,23 +687,27 @@ hipError_t bf_launch_beamform_acc(const bf_bacc_args &a_in, hipStream_t stream)
             hipLaunchKernelGGL(bf_beamform_acc_kernel<2>, grid, block, lds, stream, a);
         else
             hipLaunchKernelGGL(bf_beamform_acc_kernel<1>, grid, block, lds, stream, a);
-    } else if (a.A <= 64u && !a.unstaged) {
+    } else if (staged_form) {
         size_t stage_bytes = ((size_t)a.tiles_per_wg * a.A * 32u + 1023u) / 1024u * 1024u;
-        if (nbt < 4 && !a.no_share) { // waves that own the same tile share the making of its coefficients
+        if (nbt < 4 && !BACC_KNOB(a, no_share)) { // waves that own the same tile share the making of its coefficients
             a.share_off = (uint32_t)stage_bytes;
             stage_bytes += (size_t)nbt * 4u * 6u * 64u * sizeof(uint32_t);
         }
+#ifdef DCS_PROBES
         if (a.wg_per_cu >= 1u && a.wg_per_cu <= 5u && stage_bytes < 160u * 1024u / a.wg_per_cu) // residency cap: unused LDS
             stage_bytes = (160u * 1024u / a.wg_per_cu) & ~1023u;
+#endif
         if (a.A == 64u)
             hipLaunchKernelGGL((bf_beamform_i8_kernel<kStaged, true>), grid, block, stage_bytes, stream, a);
         else
             hipLaunchKernelGGL((bf_beamform_i8_kernel<kStaged, false>), grid, block, stage_bytes, stream, a);
-    } else if (a.A <= 64u) {
+#ifdef DCS_PROBES
+    } else if (a.A <= 64u) { // kDirect: the probes build's A/B form only
         if (a.A == 64u)
             hipLaunchKernelGGL((bf_beamform_i8_kernel<kDirect, true>), grid, block, 0, stream, a);
         else
             hipLaunchKernelGGL((bf_beamform_i8_kernel<kDirect, false>), grid, block, 0, stream, a);
+#endif
     } else { // 2 pairs x 4 registers x 4 chunks x 64 lanes x 16 bytes of partial sums
         const size_t part_bytes = 2u * 4u * 4u * 64u * 16u;
         if (a.A % 64u == 0u)

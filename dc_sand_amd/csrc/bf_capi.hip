@@ -3,6 +3,9 @@
 // throws across the boundary, prints, or starts threads.
 
 #include "../../include/dcs_beamformer.h"
+#ifdef DCS_PROBES
+#include "../../include/dcs_probes.h" // the probes build: struct dcs_probe_knobs, dcs_probe_set_knobs
+#endif
 
 #include <hip/hip_runtime.h>
 
@@ -128,8 +131,18 @@ struct dcs_bf_context {
         bool valid;
         int32_t tpb, cpb, wpc; // wpc: -1 = unlimited
     } tuned[2];
+#ifdef DCS_PROBES
+    dcs_probe_knobs probe;  // measurement knobs (include/dcs_probes.h); the product build has no such member
+#endif
 };
+// a measurement knob of the probes build; a constant 0 in the product
+#ifdef DCS_PROBES
+#define DCS_PROBE_KNOB(c, f) ((c)->probe.f)
+#else
+#define DCS_PROBE_KNOB(c, f) 0
+#endif
 
+constexpr int kTableRing = 4;
 struct dcs_bf_stream {
     dcs_bf_context *ctx;
     hipStream_t stream;
@@ -143,9 +156,18 @@ struct dcs_bf_stream {
     bf_terms_args terms_args;
     const void *terms_func;
     dim3 terms_grid, terms_block;
-    dcs_delay_vals *h_table;     // pinned staging for table updates
-    hipEvent_t table_copied;     // h_table may be rewritten after this
-    bool table_pending;
+    // host table updates: a ring of pinned staging buffers, so that a tick only blocks the host when kTableRing
+    // updates are still in flight (a table landing on every tick never waits: the copy of tick k - 4 is long done)
+    dcs_delay_vals *h_table[kTableRing];
+    hipEvent_t table_copied[kTableRing]; // h_table[i] may be rewritten after this
+    bool table_pending[kTableRing];
+    int table_next;
+    // device table updates (dcs_bf_stream_tick_*_from_global): a second instantiated graph with the slice gather
+    // (bf_gather_beams_kernel) in front of the same nodes
+    hipGraph_t ggraph;
+    hipGraphExec_t gexec;
+    hipGraphNode_t gnode_gather, gnode_terms, gnode_gen;
+    bf_gather_launch gather;
 };
 
 extern "C" {
@@ -489,12 +511,6 @@ int dcs_bf_set_tuning(dcs_bf_context *c, const dcs_bf_tuning *t)
     if (t->xcd_remap < -1 || t->xcd_remap > 1) return DCS_ERR_INVALID_ARGUMENT;
     if (t->math_mode < 0 || t->math_mode > 15) return DCS_ERR_INVALID_ARGUMENT;
     if ((t->math_mode & 4) && t->nontemporal == 0) return DCS_ERR_UNSUPPORTED; // the b16 arithmetic form exists with nontemporal stores only
-#ifdef DCS_PROBES
-    if (t->probe_pace < 0 || t->probe_pace > 4096) return DCS_ERR_INVALID_ARGUMENT;
-#else
-    // measurement knobs of the probes build (include/dcs_probes.h); the product library has neither
-    if (t->probe_nomath != 0 || t->probe_pace != 0) return DCS_ERR_UNSUPPORTED;
-#endif
     if (t->wg_per_cu < -1 || t->wg_per_cu == 1 || t->wg_per_cu > 7) return DCS_ERR_INVALID_ARGUMENT;
     c->tune = *t;
     // math_mode bit 0: keep the 5-op divide; bit 1: keep the full polynomials
@@ -537,7 +553,7 @@ uint64_t tiled_blocks(uint32_t n_pairs, bool out16, int tpb, uint32_t cpb, uint3
 // of computing them in every workgroup (bf_kernels.hip, TERMS): form 0 decides by size, form 1 never, form 3 always.
 bool want_terms_table(const dcs_bf_context *c, bool out16, const bf_geom &g, uint32_t nc, uint32_t nt)
 {
-    if (c->tune.probe_nomath || !g.ntstore || nt > kTermsInline) return false;
+    if (DCS_PROBE_KNOB(c, nomath) || !g.ntstore || nt > kTermsInline) return false;
     if (c->tune.form == 3) return true;
     if (c->tune.form != 0) return false;
     // the pre-pass is one more kernel (~2 us) and kernel boundary (~1.5 us) per call and buys 2-4 % of the main
@@ -626,10 +642,11 @@ bf_geom pick_geometry(const dcs_bf_context *c, bool out16, uint32_t nc, uint32_t
 }
 
 // Dynamic LDS a launch asks for so that exactly k workgroups fit a CU's 160 KiB (gfx950): the
-// kernel's own staging buffer (TPB tiles x 64*PPL pairs x 8 B) is static.
-uint32_t lds_pad_for(int k, bool out16, int tpb)
+// kernel's own staging buffer (TPB tiles x 64*PPL pairs x 8 B) is static -- and absent from the
+// terms-table variant, which has no LDS of its own at all.
+uint32_t lds_pad_for(int k, bool out16, int tpb, bool terms_table)
 {
-    const uint32_t kLds = 160u * 1024u, stat = (uint32_t)tpb * (out16 ? 256u : 128u) * 8u;
+    const uint32_t kLds = 160u * 1024u, stat = terms_table ? 0u : (uint32_t)tpb * (out16 ? 256u : 128u) * 8u;
     uint32_t per = (kLds / (uint32_t)k) & ~1023u; // k * per <= 160 KiB < (k + 1) * per for k <= 7
     if (per > 64u * 1024u) per = 64u * 1024u;      // default per-workgroup limit
     return per > stat ? per - stat : 0u;
@@ -660,10 +677,10 @@ int prepare_tiled(dcs_bf_context *c, bool out16, const float *dt_dev, float dt0,
     a.chan_per_block = g.cpb;
     a.xcd_remap = c->tune.xcd_remap > 0 ? 1u : 0u;
 #ifdef DCS_PROBES
-    a.pace = (uint32_t)c->tune.probe_pace;
+    a.pace = (uint32_t)c->probe.pace;
 #endif
-    const int st = (int)bf_prepare_tiled(a, dt_host, out16, tpb | (c->tune.probe_nomath ? 0x100 : 0) | (c->tuning_now ? 0x200 : 0), ntstore, l);
-    if (st == DCS_OK && g.wpc > 0) l->shared = lds_pad_for(g.wpc, out16, tpb);
+    const int st = (int)bf_prepare_tiled(a, dt_host, out16, tpb | (DCS_PROBE_KNOB(c, nomath) ? 0x100 : 0) | (c->tuning_now ? 0x200 : 0), ntstore, l);
+    if (st == DCS_OK && g.wpc > 0) l->shared = lds_pad_for(g.wpc, out16, tpb, terms_table);
     return st;
 }
 
@@ -707,6 +724,16 @@ int launch_tiled(dcs_bf_context *c, bool out16, const float *dt_dev, float dt0, 
     return (int)hipLaunchKernel(l.func, l.grid, l.block, params, l.shared, stream);
 }
 
+// Steps that block on an event, allocate or copy from pinned staging cannot be part of a stream capture.  They ask
+// first and refuse with a status, BEFORE anything is enqueued: the caller's capture stays valid (a HIP error from
+// deep inside -- hipEventSynchronize or hipMalloc under capture -- would have invalidated it).
+int refuse_if_capturing(hipStream_t stream)
+{
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    DCS_TRY(hipStreamIsCapturing(stream, &cs));
+    return cs == hipStreamCaptureStatusNone ? DCS_OK : DCS_ERR_UNSUPPORTED;
+}
+
 // The number of this beamformer call for its class words (bf_bform_terms_args::epoch): counts up, and starts again --
 // behind a clearing of the words -- before it would run out of the 30 bits it has.
 int next_flag_epoch(dcs_bf_context *c, hipStream_t s, uint32_t *epoch)
@@ -720,10 +747,15 @@ int next_flag_epoch(dcs_bf_context *c, hipStream_t s, uint32_t *epoch)
 }
 
 // The terms table (up to 64 MiB) is only needed by the rows form and the fused kernel:
-// allocate it when one of them is first used.  Not capturable (hipMalloc), like those paths.
-int ensure_terms(dcs_bf_context *c)
+// allocate it when one of them is first used.  Not capturable (hipMalloc): a first call on a
+// capturing stream is refused up front (make one call outside the capture).
+int ensure_terms(dcs_bf_context *c, hipStream_t stream)
 {
     if (c->d_terms && c->d_flags) return DCS_OK;
+    {
+        const int cap = refuse_if_capturing(stream);
+        if (cap != DCS_OK) return cap;
+    }
     if (!c->d_terms) DCS_TRY(hipMalloc((void **)&c->d_terms, (size_t)c->terms_steps * c->pairs_pad * 8u));
     if (!c->d_flags) {
         const size_t nb = (size_t)c->terms_steps * (c->pairs_pad / 64u) * 4u;
@@ -739,7 +771,7 @@ int launch_rows(dcs_bf_context *c, bool out16, const float *dt_dev, float dt0, u
                 uint32_t nc, void *d_out, hipStream_t stream)
 {
     if (nt > c->terms_steps) return DCS_ERR_INVALID_ARGUMENT;
-    int st_alloc = ensure_terms(c);
+    int st_alloc = ensure_terms(c, stream);
     if (st_alloc != DCS_OK) return st_alloc;
     bf_terms_args ta;
     std::memset(&ta, 0, sizeof(ta));
@@ -776,13 +808,13 @@ int launch_rows(dcs_bf_context *c, bool out16, const float *dt_dev, float dt0, u
     const bool xcd = c->tune.xcd_remap < 0 ? !same_tile : c->tune.xcd_remap != 0;
     a.same_tile = same_tile ? 1u : 0u;
 #ifdef DCS_PROBES
-    a.pace = (uint32_t)c->tune.probe_pace;
+    a.pace = (uint32_t)c->probe.pace;
 #endif
     if (c->tune.wg_per_cu > 0) { // rows form: only when asked for (no default limit)
         uint32_t per = (160u * 1024u / (uint32_t)c->tune.wg_per_cu) & ~1023u;
         a.lds_pad = per > 64u * 1024u ? 64u * 1024u : per;
     }
-    return (int)bf_launch_rows(a, out16, nw, rpw, ntstore, xcd, c->tune.probe_nomath != 0, stream);
+    return (int)bf_launch_rows(a, out16, nw, rpw, ntstore, xcd, DCS_PROBE_KNOB(c, nomath) != 0, stream);
 }
 
 // form 1 = tiled (long-lived waves), 2 = rows (short waves); 0 = library default
@@ -810,7 +842,8 @@ int fill_dt(const dcs_bf_context *c, const dt_source &src, uint32_t off, uint32_
     return dcs_bf_delta_times(&c->p, src.t0 + off, n, dst);
 }
 
-// Stage n fDeltaTime values through a pinned slot into device memory on `stream`.
+// Stage n fDeltaTime values through a pinned slot into device memory on `stream`.  Not capturable: callers check
+// refuse_if_capturing() before their first launch.
 int stage_dt(dcs_bf_context *c, const dt_source &src, uint32_t off, uint32_t n, hipStream_t stream, const float **dt_dev)
 {
     const int slot = c->dt_next;
@@ -840,6 +873,10 @@ int generate_slab_impl(dcs_bf_context *c, int bitwidth, const dt_source &src, ui
     const size_t step_bytes = (size_t)nc * c->n_pairs * eb;
     if (out_bytes < step_bytes * nt) return DCS_ERR_INVALID_ARGUMENT;
     hipStream_t s = as_stream(stream);
+    if (nt > 1 && (c->tune.form == 2 || nt > kDtInline)) { // the fDeltaTime values will be staged through pinned memory
+        const int cap = refuse_if_capturing(s);
+        if (cap != DCS_OK) return cap;
+    }
     for (uint32_t done = 0; done < nt;) {
         uint32_t n = (nt - done) < kDtSlotFloats ? (nt - done) : kDtSlotFloats;
         if (n > c->terms_steps) n = c->terms_steps;
@@ -893,40 +930,58 @@ int generate_impl(dcs_bf_context *c, int kernel, int bitwidth, const dt_source &
     // 0.67 ms instead of 0.84.  (NAIVE's loop is bound by the host's launch rate and ran 8 % slower spread out: it stays on
     // the caller's stream.  The pattern is capturable.)
     const bool fan = nt >= 8u && kernel == DCS_BF_MULTIPLE_CHANNELS && !want_terms_table(c, out16, pick_geometry(c, out16, C, 1), C, 1);
-    if (fan) {
-        DCS_TRY(hipEventRecord(c->fork_ev, s));
-        for (int k = 0; k < kSideStreams; k++) DCS_TRY(hipStreamWaitEvent(c->side[k], c->fork_ev, 0));
+    // every fDeltaTime is worked out (and found in range) BEFORE the first launch and before the fork: a bad time index
+    // costs nothing but the status
+    float dt_small[kDtInline];
+    float *dts = dt_small;
+    if (nt > kDtInline) {
+        dts = new (std::nothrow) float[nt];
+        if (!dts) return (int)hipErrorOutOfMemory;
+    }
+    int st = nt ? fill_dt(c, src, 0, nt, dts) : DCS_OK;
+    bool forked = false;
+    if (st == DCS_OK && fan) {
+        st = (int)hipEventRecord(c->fork_ev, s);
+        for (int k = 0; k < kSideStreams && st == DCS_OK; k++) st = (int)hipStreamWaitEvent(c->side[k], c->fork_ev, 0);
+        forked = st == DCS_OK;
     }
     // host time loop, one launch per time step: BeamformerCoefficientTest.cu:230-250
-    for (uint32_t i = 0; i < nt; i++) {
-        hipStream_t s_step = fan ? c->side[i % kSideStreams] : s;
-        float dt;
-        int st = fill_dt(c, src, i, 1, &dt);
-        if (st != DCS_OK) return st;
+    for (uint32_t i = 0; i < nt && st == DCS_OK; i++) {
+        hipStream_t s_step = forked ? c->side[i % kSideStreams] : s;
         char *dst = static_cast<char *>(d_out) + (size_t)i * step_bytes;
+#ifdef DCS_PROBES
+        if (c->probe.fail_at_step > 0 && i + 1u == (uint32_t)c->probe.fail_at_step) { // injected (error-path tests)
+            st = (int)hipErrorLaunchFailure;
+            break;
+        }
+#endif
         if (kernel == DCS_BF_NAIVE) {
             bf_naive_args a;
             std::memset(&a, 0, sizeof(a));
             a.delays = c->d_table[c->cur];
             a.out = reinterpret_cast<float *>(dst);
-            a.dt = dt;
+            a.dt = dts[i];
             a.n_pairs = c->n_pairs;
             a.c0 = 0;
             a.nc = C;
             a.k = c->k;
             st = (int)bf_launch_naive(a, s_step);
         } else {
-            st = launch_tiled(c, out16, nullptr, dt, 1, 0, C, dst, s_step);
+            st = launch_tiled(c, out16, nullptr, dts[i], 1, 0, C, dst, s_step);
         }
-        if (st != DCS_OK) return st;
     }
-    if (fan) {
+    if (dts != dt_small) delete[] dts;
+    // the join happens on EVERY way out of the loop: whatever the side streams were given runs before anything the
+    // caller enqueues next (outside a capture), and a capture is left with no unjoined fork.  The first failure is
+    // what is returned.
+    if (forked) {
         for (int k = 0; k < kSideStreams; k++) {
-            DCS_TRY(hipEventRecord(c->join_ev[k], c->side[k]));
-            DCS_TRY(hipStreamWaitEvent(s, c->join_ev[k], 0));
+            int j = (int)hipEventRecord(c->join_ev[k], c->side[k]);
+            if (j == DCS_OK) j = (int)hipStreamWaitEvent(s, c->join_ev[k], 0);
+            if (st == DCS_OK) st = j;
         }
     }
-    return DCS_OK;
+    return st;
 }
 
 // dt[i] = ts_diff(ref, cur[i]) for a (current, reference) pair per time step.
@@ -1000,12 +1055,16 @@ int beamform_impl(dcs_bf_context *c, const dt_source &src, uint32_t nt, const in
         return DCS_ERR_INVALID_ARGUMENT;
     hipStream_t s = as_stream(stream);
     {
-        int st_alloc = ensure_terms(c);
+        int st_alloc = ensure_terms(c, s);
         if (st_alloc != DCS_OK) return st_alloc;
     }
     uint32_t chunk = c->terms_steps & ~15u; // time steps per launch: what the terms table holds
     if (chunk > kDtSlotFloats) chunk = kDtSlotFloats;
     if (chunk == 0) return DCS_ERR_UNSUPPORTED;
+    if (nt > kDtInline) { // more time steps than ride in the kernel arguments: staged through pinned memory
+        const int cap = refuse_if_capturing(s);
+        if (cap != DCS_OK) return cap;
+    }
     for (uint32_t done = 0; done < nt;) {
         const uint32_t n = (nt - done) < chunk ? (nt - done) : chunk;
         // up to 256 time steps per launch: their fDeltaTime values travel in the terms kernel's arguments (the reference's
@@ -1090,7 +1149,7 @@ int beamform_acc_impl(dcs_bf_context *c, const dt_source &src, uint32_t nt, cons
     if (nt == 0) return DCS_OK;
     hipStream_t s = as_stream(stream);
     {
-        int st_alloc = ensure_terms(c);
+        int st_alloc = ensure_terms(c, s);
         if (st_alloc != DCS_OK) return st_alloc;
     }
     float dt_coeff = 0.0f; // ONE coefficient time for the whole block of samples: by value, in the kernel arguments
@@ -1129,12 +1188,16 @@ int beamform_acc_impl(dcs_bf_context *c, const dt_source &src, uint32_t nt, cons
     a.k = c->k;
     a.fp32_chain = (c->tune.math_mode & 8) ? 1u : 0u; // math_mode bit 3: the fp32 fma-chain form
 #ifdef DCS_PROBES
-    if (const char *e = std::getenv("DCS_BACC_ROUNDS")) a.max_rounds = (uint32_t)std::atoi(e); // exploration only
-    if (const char *e = std::getenv("DCS_BACC_PROBE")) a.probe = (uint32_t)std::atoi(e);
-    if (const char *e = std::getenv("DCS_BACC_UNSTAGED")) a.unstaged = (uint32_t)std::atoi(e);
-    if (const char *e = std::getenv("DCS_BACC_PLAIN")) a.plain_stores = (uint32_t)std::atoi(e);
-    if (const char *e = std::getenv("DCS_BACC_NOSHARE")) a.no_share = (uint32_t)std::atoi(e);
-    if (const char *e = std::getenv("DCS_BACC_WPC")) a.wg_per_cu = (uint32_t)std::atoi(e);
+    // the A/B switches of profiles/r02_fused.md / r03_fused.md: dcs_probe_set_knobs, or (tools/measure.py bfacc driven
+    // through the ordinary wrappers with DCS_LIB_PATH=probes/libdcs_probes.so) the environment
+    auto knob = [](int32_t v, const char *env) { const char *e = std::getenv(env); return (uint32_t)(v ? v : (e ? std::atoi(e) : 0)); };
+    a.max_rounds = knob(c->probe.bacc_rounds, "DCS_BACC_ROUNDS");
+    a.probe = knob(c->probe.bacc_probe, "DCS_BACC_PROBE");
+    a.unstaged = knob(c->probe.bacc_unstaged, "DCS_BACC_UNSTAGED");
+    a.plain_stores = knob(c->probe.bacc_plain, "DCS_BACC_PLAIN");
+    a.no_share = knob(c->probe.bacc_no_share, "DCS_BACC_NOSHARE");
+    a.wg_per_cu = knob(c->probe.bacc_wg_per_cu, "DCS_BACC_WPC");
+    a.order = knob(c->probe.bacc_order, "DCS_BACC_ORDER");
 #endif
     return (int)bf_launch_beamform_acc(a, s);
 }
@@ -1171,6 +1234,10 @@ int dcs_bf_autotune(dcs_bf_context *c, int bitwidth, void *d_out, size_t out_byt
     if (nt64 > kDtInline) nt64 = kDtInline;
     const uint32_t nt_tune = nc == (uint32_t)c->p.nr_channels && nt64 > 1 ? (uint32_t)nt64 : 1u;
     hipStream_t s = as_stream(stream);
+    {
+        const int cap = refuse_if_capturing(s); // the tuner blocks on events
+        if (cap != DCS_OK) return cap;
+    }
     dcs_bf_context::tuned_geom &slot = c->tuned[out16 ? 1 : 0];
 
     auto report = [&]() {
@@ -1330,9 +1397,107 @@ int dcs_bf_gpu_utilisation(const dcs_bf_params *p, float kernel_ms, float out[2]
 
 /* ---- streaming ---------------------------------------------------------- */
 // The graph holds ONE kernel node (the tiled generator for one time step of the
-// slab).  A tick rewrites the node's arguments in the instantiated graph --
-// fDeltaTime by value, and the delay-table buffer when a new table has landed --
-// and replays it: no host synchronisation, no memcpy node.
+// slab) -- two for slabs whose pairs' terms come from the pre-pass.  A tick rewrites the
+// nodes' arguments in the instantiated graph -- fDeltaTime by value, and the delay-table
+// buffer when a new table has landed -- and replays it: no host synchronisation, no
+// memcpy node.  A second instantiated graph has the slice gather of a device-resident
+// table in front of the same nodes (dcs_bf_stream_tick_*_from_global).
+namespace {
+
+void kernel_node_params(const bf_kernel_launch &l, void **params, hipKernelNodeParams *np)
+{
+    std::memset(np, 0, sizeof(*np));
+    np->func = const_cast<void *>(l.func);
+    np->gridDim = l.grid;
+    np->blockDim = l.block;
+    np->sharedMemBytes = l.shared;
+    np->kernelParams = params;
+    np->extra = nullptr;
+}
+
+void terms_node_params(const dcs_bf_stream *s, void **params, hipKernelNodeParams *tp)
+{
+    std::memset(tp, 0, sizeof(*tp));
+    tp->func = const_cast<void *>(s->terms_func);
+    tp->gridDim = s->terms_grid;
+    tp->blockDim = s->terms_block;
+    tp->kernelParams = params;
+}
+
+void gather_node_params(dcs_bf_stream *s, void **params, hipKernelNodeParams *gp)
+{
+    bf_gather_launch &g = s->gather;
+    params[0] = &g.local;
+    params[1] = &g.global;
+    params[2] = &g.n_ant;
+    params[3] = &g.nb_local;
+    params[4] = &g.nb_total;
+    params[5] = &g.beam_offset;
+    std::memset(gp, 0, sizeof(*gp));
+    gp->func = const_cast<void *>(g.func);
+    gp->gridDim = g.grid;
+    gp->blockDim = g.block;
+    gp->kernelParams = params;
+}
+
+// Build (gather ->) (terms ->) generator; `with_gather` selects the second graph.
+int build_stream_graph(dcs_bf_stream *s, bool with_gather, hipGraph_t *graph, hipGraphExec_t *exec, hipGraphNode_t *n_gather,
+                       hipGraphNode_t *n_terms, hipGraphNode_t *n_gen)
+{
+    DCS_TRY(hipGraphCreate(graph, 0));
+    hipGraphNode_t prev = nullptr;
+    if (with_gather) {
+        void *gparams[6];
+        hipKernelNodeParams gp;
+        gather_node_params(s, gparams, &gp);
+        DCS_TRY(hipGraphAddKernelNode(n_gather, *graph, nullptr, 0, &gp));
+        prev = *n_gather;
+    }
+    if (s->has_terms) { // pre-pass node; the generator node depends on it
+        void *tparams[] = {&s->terms_args};
+        hipKernelNodeParams tp;
+        terms_node_params(s, tparams, &tp);
+        DCS_TRY(hipGraphAddKernelNode(n_terms, *graph, prev ? &prev : nullptr, prev ? 1 : 0, &tp));
+        prev = *n_terms;
+    }
+    void *params[] = {&s->launch.args};
+    hipKernelNodeParams np;
+    kernel_node_params(s->launch, params, &np);
+    DCS_TRY(hipGraphAddKernelNode(n_gen, *graph, prev ? &prev : nullptr, prev ? 1 : 0, &np));
+    DCS_TRY(hipGraphInstantiate(exec, *graph, nullptr, nullptr, 0));
+    return DCS_OK;
+}
+
+// Rewrite the arguments of the generator (and pre-pass) node of `exec` for this tick and replay it.
+int replay(dcs_bf_stream *s, float dt, hipGraphExec_t exec, hipGraphNode_t n_gather, hipGraphNode_t n_terms, hipGraphNode_t n_gen)
+{
+    dcs_bf_context *c = s->ctx;
+    s->launch.args.a.dt0 = dt;
+    s->launch.args.a.delays = c->d_table[c->cur];
+    if (n_gather) {
+        void *gparams[6];
+        hipKernelNodeParams gp;
+        gather_node_params(s, gparams, &gp);
+        DCS_TRY(hipGraphExecKernelNodeSetParams(exec, n_gather, &gp));
+    }
+    if (s->has_terms) {
+        s->terms_args.dt0 = dt;
+        s->terms_args.dt_inline[0] = dt;
+        s->terms_args.delays = c->d_table[c->cur];
+        void *tparams[] = {&s->terms_args};
+        hipKernelNodeParams tp;
+        terms_node_params(s, tparams, &tp);
+        DCS_TRY(hipGraphExecKernelNodeSetParams(exec, n_terms, &tp));
+    }
+    void *params[] = {&s->launch.args};
+    hipKernelNodeParams np;
+    kernel_node_params(s->launch, params, &np);
+    DCS_TRY(hipGraphExecKernelNodeSetParams(exec, n_gen, &np));
+    return (int)hipGraphLaunch(exec, s->stream);
+}
+
+} // namespace
+
 int dcs_bf_stream_begin(dcs_bf_context *c, int bitwidth, uint32_t c0, uint32_t nc, void *d_out, size_t out_bytes,
                         void *stream, dcs_bf_stream **out)
 {
@@ -1344,6 +1509,10 @@ int dcs_bf_stream_begin(dcs_bf_context *c, int bitwidth, uint32_t c0, uint32_t n
     if ((uint64_t)c0 + nc > (uint64_t)c->p.nr_channels || nc == 0) return DCS_ERR_OUT_OF_RANGE;
     const bool out16 = bitwidth == DCS_BF_B16;
     if (out_bytes < (size_t)nc * c->n_pairs * (out16 ? 4 : 8)) return DCS_ERR_INVALID_ARGUMENT;
+    {
+        const int cap = refuse_if_capturing(as_stream(stream)); // allocates and instantiates
+        if (cap != DCS_OK) return cap;
+    }
 
     dcs_bf_stream *s = new (std::nothrow) dcs_bf_stream();
     if (!s) return (int)hipErrorOutOfMemory;
@@ -1360,33 +1529,17 @@ int dcs_bf_stream_begin(dcs_bf_context *c, int bitwidth, uint32_t c0, uint32_t n
             if ((st = (int)bf_prepare_terms(s->terms_args, &s->terms_func, &s->terms_grid, &s->terms_block)) != 0) break;
             if (s->terms_func == nullptr) { st = DCS_ERR_INVALID_ARGUMENT; break; }
         }
-        if ((st = (int)hipHostMalloc((void **)&s->h_table, (size_t)c->n_pairs * sizeof(dcs_delay_vals),
-                                     hipHostMallocDefault)) != 0) break;
-        if ((st = (int)hipEventCreateWithFlags(&s->table_copied, hipEventDisableTiming)) != 0) break;
-        if ((st = (int)hipGraphCreate(&s->graph, 0)) != 0) break;
-        void *params[] = {&s->launch.args};
-        hipKernelNodeParams np;
-        std::memset(&np, 0, sizeof(np));
-        np.func = const_cast<void *>(s->launch.func);
-        np.gridDim = s->launch.grid;
-        np.blockDim = s->launch.block;
-        np.sharedMemBytes = s->launch.shared;
-        np.kernelParams = params;
-        np.extra = nullptr;
-        if (s->has_terms) { // pre-pass node first; the generator node depends on it
-            void *tparams[] = {&s->terms_args};
-            hipKernelNodeParams tp;
-            std::memset(&tp, 0, sizeof(tp));
-            tp.func = const_cast<void *>(s->terms_func);
-            tp.gridDim = s->terms_grid;
-            tp.blockDim = s->terms_block;
-            tp.kernelParams = tparams;
-            if ((st = (int)hipGraphAddKernelNode(&s->terms_node, s->graph, nullptr, 0, &tp)) != 0) break;
-            if ((st = (int)hipGraphAddKernelNode(&s->node, s->graph, &s->terms_node, 1, &np)) != 0) break;
-        } else {
-            if ((st = (int)hipGraphAddKernelNode(&s->node, s->graph, nullptr, 0, &np)) != 0) break;
+        // the gather node's launch: its pointers and the global table's width are rewritten per tick, the grid never changes
+        if ((st = (int)bf_prepare_gather_beams(c->d_table[c->cur ^ 1], c->d_table[c->cur], (uint32_t)c->p.nr_stations,
+                                               (uint32_t)c->p.nr_beams, (uint32_t)c->p.nr_beams, 0u, &s->gather)) != 0) break;
+        if (s->gather.func == nullptr) { st = DCS_ERR_INVALID_ARGUMENT; break; }
+        for (int i = 0; i < kTableRing && st == 0; i++) {
+            st = (int)hipHostMalloc((void **)&s->h_table[i], (size_t)c->n_pairs * sizeof(dcs_delay_vals), hipHostMallocDefault);
+            if (st == 0) st = (int)hipEventCreateWithFlags(&s->table_copied[i], hipEventDisableTiming);
         }
-        if ((st = (int)hipGraphInstantiate(&s->exec, s->graph, nullptr, nullptr, 0)) != 0) break;
+        if (st != 0) break;
+        if ((st = build_stream_graph(s, false, &s->graph, &s->exec, nullptr, &s->terms_node, &s->node)) != 0) break;
+        if ((st = build_stream_graph(s, true, &s->ggraph, &s->gexec, &s->gnode_gather, &s->gnode_terms, &s->gnode_gen)) != 0) break;
     } while (0);
     if (st != 0) {
         dcs_bf_stream_end(s);
@@ -1404,40 +1557,18 @@ int dcs_bf_stream_tick_dt(dcs_bf_stream *s, float dt, const dcs_delay_vals *new_
     if (new_table) {
         // stage through pinned memory into the IDLE table buffer; replays already
         // queued keep reading the current one (their arguments are baked in)
-        if (s->table_pending) DCS_TRY(hipEventSynchronize(s->table_copied));
-        std::memcpy(s->h_table, new_table, (size_t)c->n_pairs * sizeof(dcs_delay_vals));
+        const int r = s->table_next;
+        s->table_next = (r + 1) % kTableRing;
+        if (s->table_pending[r]) DCS_TRY(hipEventSynchronize(s->table_copied[r])); // the copy of four updates ago
+        std::memcpy(s->h_table[r], new_table, (size_t)c->n_pairs * sizeof(dcs_delay_vals));
         const int nxt = c->cur ^ 1;
-        DCS_TRY(hipMemcpyAsync(c->d_table[nxt], s->h_table, (size_t)c->n_pairs * sizeof(dcs_delay_vals),
+        DCS_TRY(hipMemcpyAsync(c->d_table[nxt], s->h_table[r], (size_t)c->n_pairs * sizeof(dcs_delay_vals),
                                hipMemcpyHostToDevice, s->stream));
-        DCS_TRY(hipEventRecord(s->table_copied, s->stream));
-        s->table_pending = true;
+        DCS_TRY(hipEventRecord(s->table_copied[r], s->stream));
+        s->table_pending[r] = true;
         c->cur = nxt;
     }
-    s->launch.args.a.dt0 = dt;
-    s->launch.args.a.delays = c->d_table[c->cur];
-    if (s->has_terms) {
-        s->terms_args.dt0 = dt;
-        s->terms_args.dt_inline[0] = dt;
-        s->terms_args.delays = c->d_table[c->cur];
-        void *tparams[] = {&s->terms_args};
-        hipKernelNodeParams tp;
-        std::memset(&tp, 0, sizeof(tp));
-        tp.func = const_cast<void *>(s->terms_func);
-        tp.gridDim = s->terms_grid;
-        tp.blockDim = s->terms_block;
-        tp.kernelParams = tparams;
-        DCS_TRY(hipGraphExecKernelNodeSetParams(s->exec, s->terms_node, &tp));
-    }
-    void *params[] = {&s->launch.args};
-    hipKernelNodeParams np;
-    std::memset(&np, 0, sizeof(np));
-    np.func = const_cast<void *>(s->launch.func);
-    np.gridDim = s->launch.grid;
-    np.blockDim = s->launch.block;
-    np.sharedMemBytes = s->launch.shared;
-    np.kernelParams = params;
-    DCS_TRY(hipGraphExecKernelNodeSetParams(s->exec, s->node, &np));
-    return (int)hipGraphLaunch(s->exec, s->stream);
+    return replay(s, dt, s->exec, nullptr, s->terms_node, s->node);
 }
 
 int dcs_bf_stream_tick(dcs_bf_stream *s, uint64_t t, const dcs_delay_vals *new_table)
@@ -1459,16 +1590,72 @@ int dcs_bf_stream_tick_at(dcs_bf_stream *s, const struct timespec *cur, const st
     return dcs_bf_stream_tick_dt(s, dt, new_table);
 }
 
+int dcs_bf_stream_tick_dt_from_global(dcs_bf_stream *s, float dt, const void *d_global, uint32_t nb_total, uint32_t beam_offset)
+{
+    if (!s || !d_global) return DCS_ERR_INVALID_ARGUMENT;
+    dcs_bf_context *c = s->ctx;
+    DCS_CHECK_DEVICE(c);
+    if ((uint64_t)beam_offset + (uint64_t)c->p.nr_beams > nb_total) return DCS_ERR_OUT_OF_RANGE;
+    if ((reinterpret_cast<uintptr_t>(d_global) & 15u) != 0) return DCS_ERR_INVALID_ARGUMENT;
+    // the gather node writes the IDLE table buffer (replays already queued read the current one), the nodes
+    // behind it read it: all inside one graph launch, ordered by the graph's edges
+    const int nxt = c->cur ^ 1;
+    s->gather.local = c->d_table[nxt];
+    s->gather.global = static_cast<const dcs_delay_vals *>(d_global);
+    s->gather.nb_total = nb_total;
+    s->gather.beam_offset = beam_offset;
+    c->cur = nxt;
+    return replay(s, dt, s->gexec, s->gnode_gather, s->gnode_terms, s->gnode_gen);
+}
+
+int dcs_bf_stream_tick_from_global(dcs_bf_stream *s, uint64_t t, const void *d_global, uint32_t nb_total, uint32_t beam_offset)
+{
+    if (!s) return DCS_ERR_INVALID_ARGUMENT;
+    float dt;
+    const int st = dcs_bf_delta_times(&s->ctx->p, t, 1, &dt);
+    if (st != DCS_OK) return st;
+    return dcs_bf_stream_tick_dt_from_global(s, dt, d_global, nb_total, beam_offset);
+}
+
+int dcs_bf_stream_tick_at_from_global(dcs_bf_stream *s, const struct timespec *cur, const struct timespec *ref,
+                                      const void *d_global, uint32_t nb_total, uint32_t beam_offset)
+{
+    if (!s) return DCS_ERR_INVALID_ARGUMENT;
+    float dt;
+    const int st = dcs_bf_ts_diff(ref, cur, &dt);
+    if (st != DCS_OK) return st;
+    return dcs_bf_stream_tick_dt_from_global(s, dt, d_global, nb_total, beam_offset);
+}
+
 int dcs_bf_stream_end(dcs_bf_stream *s)
 {
     if (!s) return DCS_OK;
     (void)hipStreamSynchronize(s->stream);
     if (s->exec) (void)hipGraphExecDestroy(s->exec);
     if (s->graph) (void)hipGraphDestroy(s->graph);
-    if (s->table_copied) (void)hipEventDestroy(s->table_copied);
-    if (s->h_table) (void)hipHostFree(s->h_table);
+    if (s->gexec) (void)hipGraphExecDestroy(s->gexec);
+    if (s->ggraph) (void)hipGraphDestroy(s->ggraph);
+    for (int i = 0; i < kTableRing; i++) {
+        if (s->table_copied[i]) (void)hipEventDestroy(s->table_copied[i]);
+        if (s->h_table[i]) (void)hipHostFree(s->h_table[i]);
+    }
     delete s;
     return DCS_OK;
 }
+
+#ifdef DCS_PROBES
+/* include/dcs_probes.h -- the probes build only */
+int dcs_probe_set_knobs(dcs_bf_context *c, const dcs_probe_knobs *k)
+{
+    if (!c) return DCS_ERR_INVALID_ARGUMENT;
+    if (!k) {
+        std::memset(&c->probe, 0, sizeof(c->probe));
+        return DCS_OK;
+    }
+    if (k->pace < 0 || k->pace > 4096 || k->fail_at_step < 0) return DCS_ERR_INVALID_ARGUMENT;
+    c->probe = *k;
+    return DCS_OK;
+}
+#endif
 
 } // extern "C"

@@ -140,20 +140,26 @@ struct bf_bacc_args {
     uint32_t A, B, C, nT16;
     uint32_t fp32_chain;   // 0: exact fixed-point contraction on the int8 matrix pipe; 1: fp32 fma chain (v_mfma_f32_16x16x4_f32)
     uint32_t share_off;    // staged int8 form: LDS offset of the coefficient exchange (filled by the launcher; 0 = none)
-    // A/B switches of the measurements in profiles/r02_fused.md; all 0 in the product (bf_capi.hip sets them from the
-    // environment in the probes build only):
+#ifdef DCS_PROBES
+    // A/B switches of the measurements in profiles/r02_fused.md / r03_fused.md (include/dcs_probes.h: dcs_probe_knobs);
+    // the product build has none of them -- BACC_KNOB() below reads as a constant 0 there
     uint32_t max_rounds;   // cap on the rounds of sample blocks per workgroup (0 = the launcher's choice)
     uint32_t no_share;     // staged int8 form: every wave makes all its coefficients
     uint32_t plain_stores; // int8 form: ordinary instead of nontemporal stores
     uint32_t wg_per_cu;    // staged int8 form: at most this many workgroups resident per CU (0 = as many as fit)
     uint32_t unstaged;     // int8 form, <= 64 antennas: operands straight from global memory instead of through LDS
-#ifdef DCS_PROBES
+    uint32_t order;        // workgroup numbering: 1 = round 2's (beam group fastest, channels spread over the XCDs)
     uint32_t probe;        // 1 = stores only, 2 = loads and stores without arithmetic, 3 = stores without coefficients either,
                            // 4 = as 3 with one contiguous KiB per store instruction
 #endif
     uint32_t tiles_per_wg, n_bgroups, n_tgroups, nbt_log2; // filled by the launcher
     dcs_bf_consts k;
 };
+#ifdef DCS_PROBES
+#define BACC_KNOB(a, f) ((a).f)
+#else
+#define BACC_KNOB(a, f) 0u
+#endif
 hipError_t bf_launch_beamform_acc(const bf_bacc_args &a, hipStream_t stream);
 hipError_t bf_warm_module_mfma();
 
@@ -168,7 +174,17 @@ struct bf_naive_args {
 };
 hipError_t bf_launch_naive(const bf_naive_args &a, hipStream_t stream);
 
-// local[a][b] = global[a][beam_offset + b]
+// local[a][b] = global[a][beam_offset + b]: the launch resolved but not enqueued (the kernel takes these six
+// scalars as its parameters, in this order; a hipGraph kernel node is built from it -- dcs_bf_stream_tick_*_from_global)
+struct bf_gather_launch {
+    const void *func; // nullptr: nothing to launch
+    dim3 grid, block;
+    dcs_delay_vals *local;
+    const dcs_delay_vals *global;
+    uint32_t n_ant, nb_local, nb_total, beam_offset;
+};
+hipError_t bf_prepare_gather_beams(dcs_delay_vals *local, const dcs_delay_vals *global, uint32_t n_ant, uint32_t n_beams_local,
+                                   uint32_t n_beams_total, uint32_t beam_offset, bf_gather_launch *out);
 hipError_t bf_launch_gather_beams(dcs_delay_vals *local, const dcs_delay_vals *global,
                                   uint32_t n_ant, uint32_t n_beams_local, uint32_t n_beams_total,
                                   uint32_t beam_offset, hipStream_t stream);

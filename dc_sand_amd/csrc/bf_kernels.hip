@@ -775,16 +775,34 @@ hipError_t bf_launch_naive(const bf_naive_args &a, hipStream_t stream)
     return hipGetLastError();
 }
 
+hipError_t bf_prepare_gather_beams(dcs_delay_vals *local, const dcs_delay_vals *global, uint32_t n_ant, uint32_t n_beams_local,
+                                   uint32_t n_beams_total, uint32_t beam_offset, bf_gather_launch *out)
+{
+    out->func = nullptr;
+    out->local = local;
+    out->global = global;
+    out->n_ant = n_ant;
+    out->nb_local = n_beams_local;
+    out->nb_total = n_beams_total;
+    out->beam_offset = beam_offset;
+    const uint64_t n = (uint64_t)n_ant * n_beams_local;
+    if (n == 0) return hipSuccess;
+    if (n > 0x7fffffffull) return hipErrorInvalidValue;
+    out->func = reinterpret_cast<const void *>(&bf_gather_beams_kernel);
+    out->grid = dim3((uint32_t)((n + kBlock - 1) / kBlock));
+    out->block = dim3(kBlock);
+    return hipSuccess;
+}
+
 hipError_t bf_launch_gather_beams(dcs_delay_vals *local, const dcs_delay_vals *global, uint32_t n_ant,
                                   uint32_t n_beams_local, uint32_t n_beams_total, uint32_t beam_offset,
                                   hipStream_t stream)
 {
-    const uint64_t n = (uint64_t)n_ant * n_beams_local;
-    if (n == 0) return hipSuccess;
-    const dim3 grid((uint32_t)((n + kBlock - 1) / kBlock));
-    hipLaunchKernelGGL(bf_gather_beams_kernel, grid, dim3(kBlock), 0, stream, local, global, n_ant,
-                       n_beams_local, n_beams_total, beam_offset);
-    return hipGetLastError();
+    bf_gather_launch g;
+    const hipError_t e = bf_prepare_gather_beams(local, global, n_ant, n_beams_local, n_beams_total, beam_offset, &g);
+    if (e != hipSuccess || g.func == nullptr) return e;
+    void *params[] = {&g.local, &g.global, &g.n_ant, &g.nb_local, &g.nb_total, &g.beam_offset};
+    return hipLaunchKernel(g.func, g.grid, g.block, params, 0, stream);
 }
 
 namespace {

@@ -114,6 +114,11 @@ def memcpy_dtoh(dst: np.ndarray, src, stream=None, sync: bool = True, nbytes: in
         stream_synchronize(stream)
 
 
+def memcpy_dtod(dst, src, nbytes: int, stream=None) -> None:
+    """Device-to-device copy, asynchronous on ``stream`` (``dcs_memcpy_dtod``)."""
+    check(_lib.lib().dcs_memcpy_dtod(c_void_p(int(dst)), c_void_p(int(src)), int(nbytes), _s(stream)), "dcs_memcpy_dtod")
+
+
 def memcpy2d_dtoh(dst: np.ndarray, dst_pitch: int, src, src_pitch: int, row_bytes: int, nrows: int, stream=None) -> None:
     check(
         _lib.lib().dcs_memcpy2d_dtoh(_host_ptr(dst), dst_pitch, c_void_p(int(src)), src_pitch, row_bytes, nrows, _s(stream)),

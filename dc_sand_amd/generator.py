@@ -188,26 +188,27 @@ class SteeringCoefficientGenerator:
                 "dcs_bf_beamform_accumulated_dt",
             )
 
+    TUNING_FIELDS = ("form", "nontemporal", "chan_per_block", "tiles_per_block", "waves_per_block", "rows_per_wave",
+                     "xcd_remap", "rows_same_tile", "math_mode", "wg_per_cu")
+    _TUNING_DEFAULTS = (0, -1, 0, 0, 0, 0, -1, -1, 0, 0)
+
     def set_tuning(self, form: int = 0, nontemporal: int = -1, chan_per_block: int = 0, tiles_per_block: int = 0,
-                   waves_per_block: int = 0, rows_per_wave: int = 0, xcd_remap: int = -1, probe_nomath: bool = False,
-                   rows_same_tile: int = -1, probe_pace: int = 0, math_mode: int = 0, wg_per_cu: int = 0) -> None:
-        """``struct dcs_bf_tuning``; ``set_tuning()`` restores the defaults.  ``probe_nomath`` / ``probe_pace`` are
-        honoured only by the probes build of the library (include/dcs_probes.h); the product library refuses them."""
+                   waves_per_block: int = 0, rows_per_wave: int = 0, xcd_remap: int = -1, rows_same_tile: int = -1,
+                   math_mode: int = 0, wg_per_cu: int = 0) -> None:
+        """``struct dcs_bf_tuning`` (ABI 3: ten ``int32_t``); ``set_tuning()`` restores the defaults.  The measurement
+        knobs of ABI 2 (``probe_nomath`` / ``probe_pace``) are ``probes.dcs_probes.set_knobs`` of the probes build now."""
         vals = (form, nontemporal, chan_per_block, tiles_per_block, waves_per_block, rows_per_wave,
-                xcd_remap, 1 if probe_nomath else 0, rows_same_tile, probe_pace, math_mode, wg_per_cu)
-        if vals == (0, -1, 0, 0, 0, 0, -1, 0, -1, 0, 0, 0):  # all defaults: NULL, which also forgets dcs_bf_autotune's result
+                xcd_remap, rows_same_tile, math_mode, wg_per_cu)
+        if vals == self._TUNING_DEFAULTS:  # all defaults: NULL, which also forgets dcs_bf_autotune's result
             check(_lib.lib().dcs_bf_set_tuning(c_void_p(self._h), c_void_p(None)), "dcs_bf_set_tuning")
             return
-        t = (ctypes.c_int32 * 12)(*vals)
+        t = (ctypes.c_int32 * len(self.TUNING_FIELDS))(*vals)
         check(_lib.lib().dcs_bf_set_tuning(c_void_p(self._h), ctypes.cast(t, c_void_p)), "dcs_bf_set_tuning")
-
-    TUNING_FIELDS = ("form", "nontemporal", "chan_per_block", "tiles_per_block", "waves_per_block", "rows_per_wave",
-                     "xcd_remap", "probe_nomath", "rows_same_tile", "probe_pace", "math_mode", "wg_per_cu")
 
     def autotune(self, d_out, out_bytes: int, bitwidth: int = B32, stream=None) -> dict:
         """``dcs_bf_autotune``: time the tiled form's geometries on this device for this
         shape, keep the fastest for this context, return the chosen knobs."""
-        t = (ctypes.c_int32 * 12)()
+        t = (ctypes.c_int32 * len(self.TUNING_FIELDS))()
         check(
             _lib.lib().dcs_bf_autotune(c_void_p(self._h), int(bitwidth), c_void_p(int(d_out)), int(out_bytes), _s(stream),
                                        ctypes.cast(t, c_void_p)),
@@ -274,6 +275,30 @@ class CoefficientStream:
         cur = _lib.Timespec(int(current_time[0]), int(current_time[1]))
         ref = _lib.Timespec(int(reference_time[0]), int(reference_time[1]))
         check(_lib.lib().dcs_bf_stream_tick_at(c_void_p(self._h), byref(cur), byref(ref), ptr), "dcs_bf_stream_tick_at")
+
+    # -- the same ticks with the new table already on the device (a global [NR_STATIONS][nr_beams_total] table, e.g.
+    #    just broadcast by RCCL; this context owns beams [beam_offset, beam_offset + NR_BEAMS)): gathered by a node of
+    #    the replayed graph, no host staging (``dcs_bf_stream_tick_*_from_global``)
+    def _global_args(self, d_global_table, nr_beams_total, beam_offset):
+        nb = self._gen.params.NR_BEAMS if nr_beams_total is None else nr_beams_total
+        return c_void_p(int(d_global_table)), int(nb), int(beam_offset)
+
+    def tick_from_global(self, t: int, d_global_table, nr_beams_total: int | None = None, beam_offset: int = 0) -> None:
+        check(_lib.lib().dcs_bf_stream_tick_from_global(c_void_p(self._h), int(t), *self._global_args(d_global_table, nr_beams_total, beam_offset)),
+              "dcs_bf_stream_tick_from_global")
+
+    def tick_dt_from_global(self, dt: float, d_global_table, nr_beams_total: int | None = None, beam_offset: int = 0) -> None:
+        check(_lib.lib().dcs_bf_stream_tick_dt_from_global(c_void_p(self._h), float(np.float32(dt)),
+                                                           *self._global_args(d_global_table, nr_beams_total, beam_offset)),
+              "dcs_bf_stream_tick_dt_from_global")
+
+    def tick_at_from_global(self, current_time, reference_time, d_global_table, nr_beams_total: int | None = None,
+                            beam_offset: int = 0) -> None:
+        cur = _lib.Timespec(int(current_time[0]), int(current_time[1]))
+        ref = _lib.Timespec(int(reference_time[0]), int(reference_time[1]))
+        check(_lib.lib().dcs_bf_stream_tick_at_from_global(c_void_p(self._h), byref(cur), byref(ref),
+                                                           *self._global_args(d_global_table, nr_beams_total, beam_offset)),
+              "dcs_bf_stream_tick_at_from_global")
 
     def end(self) -> None:
         if self._h:

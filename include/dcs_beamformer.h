@@ -12,7 +12,10 @@
  * 256 time steps per call -- their fDeltaTime values travel in the kernel
  * arguments; the beamformers after a first plain call, which allocates their
  * terms table -- ; longer calls and the rows form stage tables through pinned
- * memory and are not capturable); nothing here starts host threads.
+ * memory and are not capturable).  A call that cannot be captured says so UP
+ * FRONT: on a capturing stream it returns DCS_ERR_UNSUPPORTED before it has
+ * enqueued anything, and the capture stays valid (it can be ended, or carried
+ * on with capturable calls).  Nothing here starts host threads.
  *
  * Each declaration cites the reference interface it replaces (paths relative
  * to the reference root; "BCT" = beamformer_coefficient_generator/
@@ -34,7 +37,7 @@ extern "C" {
 /* the libraries are built -fvisibility=hidden: only what this header declares is exported */
 #pragma GCC visibility push(default)
 
-#define DCS_BF_ABI_VERSION 2
+#define DCS_BF_ABI_VERSION 3 /* 3: dcs_bf_tuning without measurement fields; stream ticks from a device-resident table */
 
 /* ---- status codes ------------------------------------------------------- */
 #define DCS_OK 0
@@ -269,7 +272,7 @@ int dcs_bf_beamform_accumulated_dt(dcs_bf_context *ctx, float dt_coeff, uint32_t
  *           stream the tensor in address order.
  * MULTIPLE_CHANNELS always uses the tiled form (the reference's per-time-step shape); from 8 time steps on its
  * launches are spread over four internal streams between a fork and a join on the caller's stream. */
-struct dcs_bf_tuning {
+struct dcs_bf_tuning { /* ABI 3: ten int32_t; the measurement knobs of ABI 2 live in include/dcs_probes.h now */
     int32_t form;            /* 0 default (tiled; terms table for large launches), 1 tiled with per-workgroup terms,
                               * 2 rows, 3 tiled with the terms table */
     int32_t nontemporal;     /* -1 default, 0 plain stores, 1 nontemporal */
@@ -278,10 +281,8 @@ struct dcs_bf_tuning {
     int32_t waves_per_block; /* form 2: 4, 8, 16 */
     int32_t rows_per_wave;   /* form 2: 1..4 */
     int32_t xcd_remap;       /* -1 default, 0, 1: workgroups sharing blockIdx % 8 (one XCD) take consecutive work */
-    int32_t probe_nomath;    /* must be 0 (libdcs_probes.so only: addressing and stores, no arithmetic) */
     int32_t rows_same_tile;  /* form 2: -1 default, 0 = the waves take adjacent tiles, 1 = they share one tile and
                               * interleave rows */
-    int32_t probe_pace;      /* must be 0 (libdcs_probes.so only: 64-cycle sleeps before each store) */
     int32_t math_mode;       /* arithmetic forms.  Bits 0 and 1 are A/B switches that never change a bit of the output:
                               * bit 0 = keep the 5-op divide even where the 3-op form was verified exact for this
                               * divisor; bit 1 = keep the full-degree polynomials even where the low-degree ones are
@@ -328,7 +329,9 @@ int dcs_bf_gpu_utilisation(const struct dcs_bf_params *p, float kernel_ms, float
  * node's arguments in the instantiated graph (fDeltaTime of time index t; the
  * delay-table buffer) and replays it on `stream` -- no host synchronisation.  A
  * non-NULL new_table is staged into the idle table buffer first and used from
- * this tick on (time-varying delay polynomials, double-buffered). */
+ * this tick on (time-varying delay polynomials, double-buffered; the host copy goes
+ * through a ring of four pinned buffers, so a tick blocks the host only when four
+ * table updates are still in flight). */
 typedef struct dcs_bf_stream dcs_bf_stream;
 int dcs_bf_stream_begin(dcs_bf_context *ctx, int bitwidth, uint32_t c0, uint32_t nc, void *d_out,
                         size_t out_bytes, void *stream, dcs_bf_stream **s);
@@ -339,6 +342,21 @@ int dcs_bf_stream_tick(dcs_bf_stream *s, uint64_t t, const struct dcs_delay_vals
 int dcs_bf_stream_tick_dt(dcs_bf_stream *s, float dt, const struct dcs_delay_vals *new_table);
 int dcs_bf_stream_tick_at(dcs_bf_stream *s, const struct timespec *cur, const struct timespec *ref,
                           const struct dcs_delay_vals *new_table);
+/* The same ticks with the new delay table ALREADY ON THE DEVICE -- the shape of the reference's kernels, whose
+ * table is a device pointer argument (BeamformerKernels.cuh:38-42, 81-86), and what the multi-GPU design
+ * produces: d_global_table is the GLOBAL table [nr_stations][nr_beams_total] an RCCL broadcast has just
+ * landed (16-byte aligned), of which this context owns beams [beam_offset, beam_offset + nr_beams), as in
+ * dcs_bf_set_delays_from_global (nr_beams_total = nr_beams, beam_offset = 0: a plain device table).  The
+ * slice is gathered into the idle table buffer by a kernel node IN the replayed graph (its arguments are
+ * rewritten per tick like the others): no host staging, no event, no synchronisation -- BASELINE
+ * configs[3] (beam-sharded, table by broadcast) and configs[4] (streaming) compose without a D2H round
+ * trip.  The table must stay unchanged until the stream has passed this tick. */
+int dcs_bf_stream_tick_from_global(dcs_bf_stream *s, uint64_t t, const void *d_global_table,
+                                   uint32_t nr_beams_total, uint32_t beam_offset);
+int dcs_bf_stream_tick_dt_from_global(dcs_bf_stream *s, float dt, const void *d_global_table,
+                                      uint32_t nr_beams_total, uint32_t beam_offset);
+int dcs_bf_stream_tick_at_from_global(dcs_bf_stream *s, const struct timespec *cur, const struct timespec *ref,
+                                      const void *d_global_table, uint32_t nr_beams_total, uint32_t beam_offset);
 int dcs_bf_stream_end(dcs_bf_stream *s);
 
 #pragma GCC visibility pop

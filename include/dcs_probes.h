@@ -3,10 +3,11 @@
  * NOT part of the product ABI (include/dcs_beamformer.h): nothing a caller of the hot path
  * needs is here.  Library: probes/libdcs_probes.so (`python -m probes.build`), which holds
  *   - the dcs_probe_* entry points below (probes/bf_probes.hip), and
- *   - a second build of the product sources with -DDCS_PROBES, i.e. the whole dcs_bf_* API
- *     with dcs_bf_tuning::probe_nomath (store-only skeleton of the generator) and
- *     dcs_bf_tuning::probe_pace (sleep before each store) honoured -- libdcs_beamformer.so
- *     answers DCS_ERR_UNSUPPORTED to either.
+ *   - a second build of the product sources with -DDCS_PROBES, i.e. the whole dcs_bf_* API plus the
+ *     measurement knobs of struct dcs_probe_knobs below (store-only skeleton of the generator, sleeps
+ *     before each store, the coefficient-reuse beamformer's A/B switches, an injected launch failure for
+ *     the error-path tests).  libdcs_beamformer.so has none of them: they are compiled out of its
+ *     kernels, argument structs and context (ABI 3; ABI 2 carried two of them in dcs_bf_tuning).
  * Users: tests/ (device sincos sweep, whole-tensor checksum of the full-size configs) and
  * tools/measure.py (the store-pattern studies behind profiles/r01_store_patterns.md).
  */
@@ -20,6 +21,24 @@ extern "C" {
 #endif
 /* the libraries are built -fvisibility=hidden: only what this header declares is exported */
 #pragma GCC visibility push(default)
+
+/* Measurement knobs of a context of THIS library (all 0 = the product's behaviour).  NULL resets them. */
+struct dcs_probe_knobs {
+    int32_t nomath;         /* generator: addressing and stores only, no arithmetic (the store ceiling of a geometry) */
+    int32_t pace;           /* generator: 64-cycle sleeps before each store of the fast loop (0..4096) */
+    int32_t fail_at_step;   /* per-time-step launch loops (NAIVE, MULTIPLE_CHANNELS): the launch of step
+                             * fail_at_step - 1 reports hipErrorLaunchFailure without being enqueued (0 = never) */
+    /* dcs_bf_beamform_accumulated, int8 form (profiles/r02_fused.md, r03_fused.md): */
+    int32_t bacc_probe;     /* 1 = stores only, 2 = loads and stores without arithmetic, 3 = stores without
+                             * coefficients either, 4 = as 3 with one contiguous KiB per store instruction */
+    int32_t bacc_rounds;    /* cap on the rounds of sample blocks per workgroup (0 = the launcher's choice) */
+    int32_t bacc_no_share;  /* staged form: every wave makes all its coefficients */
+    int32_t bacc_plain;     /* ordinary instead of nontemporal stores */
+    int32_t bacc_wg_per_cu; /* staged form: at most this many workgroups resident per CU */
+    int32_t bacc_unstaged;  /* <= 64 antennas: operands straight from global memory instead of through LDS */
+    int32_t bacc_order;     /* workgroup numbering: 0 = the product's (XCD-aware), 1 = round 2's (beam group fastest) */
+};
+int dcs_probe_set_knobs(dcs_bf_context *ctx, const struct dcs_probe_knobs *k);
 
 /* Device evaluation of the two sincos forms on n arguments:
  * which = 0 the library's fast path (full polynomials), 1 __ocml_sincos_f32, 2 the fp64

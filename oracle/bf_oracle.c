@@ -459,12 +459,13 @@ void dcs_oracle_simulate_antenna_data(int8_t *out, size_t nbytes)
     for (size_t i = 0; i < nbytes; i++) out[i] = (int8_t)i;
 }
 
-/* BeamformerCoefficientTest.cu:294-337 (ordering :311) + :363-414 */
+/* BeamformerCoefficientTest.cu:294-337 (ordering :311) + :363-414; channels [c0, c0 + nc), the two tensors pointing at
+ * that slab (the reference's loop is c0 = 0, nc = NR_CHANNELS) */
 static void beamform_impl(const struct dcs_oracle_params *p,
-                          const struct dcs_oracle_delay_vals *delays, const float *dt, size_t nt,
+                          const struct dcs_oracle_delay_vals *delays, const float *dt, size_t nt, size_t c0, size_t nc,
                           const int8_t *pi8InAntData, float *pfCorrectBeams)
 {
-    const size_t NR_CHANNELS = (size_t)p->nr_channels;
+    const size_t NR_CHANNELS = nc;
     const size_t NR_STATIONS = (size_t)p->nr_stations;
     const size_t NR_BEAMS = (size_t)p->nr_beams;
     const size_t NR_SAMPLES_PER_CHANNEL = nt;
@@ -480,7 +481,7 @@ static void beamform_impl(const struct dcs_oracle_params *p,
                     float fBeamSumImag = 0;
                     for (size_t a = 0; a < NR_STATIONS; a++) {
                         float fRealSteeringCoeff, fImagSteeringCoeff;
-                        dcs_oracle_coeff(p, delays[b * NR_STATIONS + a], fDeltaTime, c,
+                        dcs_oracle_coeff(p, delays[b * NR_STATIONS + a], fDeltaTime, c0 + c,
                                          &fRealSteeringCoeff, &fImagSteeringCoeff);
                         size_t ulAntSampleIndex = 2 * (c * NR_SAMPLES_PER_CHANNEL * NR_STATIONS + t_ex * NR_STATIONS * INTERNAL_TIME_SAMPLES + a * INTERNAL_TIME_SAMPLES + t_in);
                         int8_t iRealAntSample = pi8InAntData[ulAntSampleIndex];
@@ -500,7 +501,7 @@ void dcs_oracle_beamform(const struct dcs_oracle_params *p,
                          const struct dcs_oracle_delay_vals *delays, size_t nt,
                          const int8_t *pi8InAntData, float *pfCorrectBeams)
 {
-    beamform_impl(p, delays, NULL, nt, pi8InAntData, pfCorrectBeams);
+    beamform_impl(p, delays, NULL, nt, 0, (size_t)p->nr_channels, pi8InAntData, pfCorrectBeams);
 }
 
 /* The same with fDeltaTime of each of the nt samples given (cf. dcs_oracle_generate_dt). */
@@ -508,7 +509,16 @@ void dcs_oracle_beamform_dt(const struct dcs_oracle_params *p,
                             const struct dcs_oracle_delay_vals *delays, const float *dt, size_t nt,
                             const int8_t *pi8InAntData, float *pfCorrectBeams)
 {
-    beamform_impl(p, delays, dt, nt, pi8InAntData, pfCorrectBeams);
+    beamform_impl(p, delays, dt, nt, 0, (size_t)p->nr_channels, pi8InAntData, pfCorrectBeams);
+}
+
+/* Channels [c0, c0 + nc) of dcs_oracle_beamform_dt (dt == NULL: time indices 0 .. nt-1 as dcs_oracle_beamform);
+ * pi8InAntData / pfCorrectBeams point at the slab. */
+void dcs_oracle_beamform_slab(const struct dcs_oracle_params *p,
+                              const struct dcs_oracle_delay_vals *delays, const float *dt, size_t nt, size_t c0, size_t nc,
+                              const int8_t *pi8InAntData, float *pfCorrectBeams)
+{
+    beamform_impl(p, delays, dt, nt, c0, nc, pi8InAntData, pfCorrectBeams);
 }
 
 /* BeamformerCoefficientTest.cu:363-414 with the coefficient HELD: the steering coefficient of
@@ -516,21 +526,23 @@ void dcs_oracle_beamform_dt(const struct dcs_oracle_params *p,
  * and applied to all nt samples -- what ACCUMULATIONS_BEFORE_NEW_COEFFS (BeamformerParameters.h:17;
  * the utilisation model :426-448) assumes of a deployed beamformer; the reference has no kernel for it.
  * The sums are the verifier's: antenna order, fBeamSum += coeff * sample (multiply and add rounded
- * separately). */
-void dcs_oracle_beamform_accumulated(const struct dcs_oracle_params *p,
-                                     const struct dcs_oracle_delay_vals *delays, float dt_coeff, size_t nt,
-                                     const int8_t *pi8InAntData, float *pfCorrectBeams)
+ * separately).
+ *
+ * _slab: channels [c0, c0 + nc) of it; pi8InAntData / pfCorrectBeams point at the slab (its first channel is c0), so
+ * that a few channels of a large problem can be checked without evaluating all of it. */
+void dcs_oracle_beamform_accumulated_slab(const struct dcs_oracle_params *p,
+                                          const struct dcs_oracle_delay_vals *delays, float dt_coeff, size_t nt,
+                                          size_t c0, size_t nc, const int8_t *pi8InAntData, float *pfCorrectBeams)
 {
-    const size_t NR_CHANNELS = (size_t)p->nr_channels;
     const size_t NR_STATIONS = (size_t)p->nr_stations;
     const size_t NR_BEAMS = (size_t)p->nr_beams;
     const size_t NR_SAMPLES_PER_CHANNEL = nt;
     const size_t INTERNAL_TIME_SAMPLES = 16;
     float *coeff = malloc(NR_STATIONS * 2 * sizeof(float));
-    for (size_t c = 0; c < NR_CHANNELS; c++) {
+    for (size_t c = 0; c < nc; c++) {
         for (size_t b = 0; b < NR_BEAMS; b++) {
             for (size_t a = 0; a < NR_STATIONS; a++)
-                dcs_oracle_coeff(p, delays[b * NR_STATIONS + a], dt_coeff, c, &coeff[2 * a], &coeff[2 * a + 1]);
+                dcs_oracle_coeff(p, delays[b * NR_STATIONS + a], dt_coeff, c0 + c, &coeff[2 * a], &coeff[2 * a + 1]);
             for (size_t t = 0; t < NR_SAMPLES_PER_CHANNEL; t++) {
                 const size_t t_ex = t / INTERNAL_TIME_SAMPLES, t_in = t % INTERNAL_TIME_SAMPLES;
                 size_t iBeamIndex = c * NR_SAMPLES_PER_CHANNEL * NR_BEAMS + t_ex * NR_BEAMS * INTERNAL_TIME_SAMPLES + b * INTERNAL_TIME_SAMPLES + t_in;
@@ -549,6 +561,13 @@ void dcs_oracle_beamform_accumulated(const struct dcs_oracle_params *p,
         }
     }
     free(coeff);
+}
+
+void dcs_oracle_beamform_accumulated(const struct dcs_oracle_params *p,
+                                     const struct dcs_oracle_delay_vals *delays, float dt_coeff, size_t nt,
+                                     const int8_t *pi8InAntData, float *pfCorrectBeams)
+{
+    dcs_oracle_beamform_accumulated_slab(p, delays, dt_coeff, nt, 0, (size_t)p->nr_channels, pi8InAntData, pfCorrectBeams);
 }
 
 /* IEEE binary16 round-to-nearest-even of an fp32 (what __floats2half2_rn does

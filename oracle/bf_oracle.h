@@ -177,12 +177,21 @@ void dcs_oracle_beamform_dt(const struct dcs_oracle_params *p,
                             const struct dcs_oracle_delay_vals *delays, const float *dt, size_t nt,
                             const int8_t *antenna_data, float *out);
 
+/* Channels [c0, c0 + nc) of dcs_oracle_beamform_dt (dt == NULL: time indices 0 .. nt-1); tensors point at the slab. */
+void dcs_oracle_beamform_slab(const struct dcs_oracle_params *p,
+                              const struct dcs_oracle_delay_vals *delays, const float *dt, size_t nt, size_t c0, size_t nc,
+                              const int8_t *antenna_data, float *out);
+
 /* The verifier's beamformer (:363-414) with the coefficient HELD at one fDeltaTime for all nt samples
  * (what ACCUMULATIONS_BEFORE_NEW_COEFFS models; the reference has no kernel for it): the expectation of
  * dcs_bf_beamform_accumulated.  Same tensors and table ordering as dcs_oracle_beamform. */
 void dcs_oracle_beamform_accumulated(const struct dcs_oracle_params *p,
                                      const struct dcs_oracle_delay_vals *delays, float dt_coeff, size_t nt,
                                      const int8_t *antenna_data, float *out);
+/* Channels [c0, c0 + nc) of it; antenna_data / out point at the slab (first channel c0). */
+void dcs_oracle_beamform_accumulated_slab(const struct dcs_oracle_params *p,
+                                          const struct dcs_oracle_delay_vals *delays, float dt_coeff, size_t nt,
+                                          size_t c0, size_t nc, const int8_t *antenna_data, float *out);
 
 /* fp16 (f2): IEEE binary16 round-to-nearest-even of an fp32, as
  * __floats2half2_rn does per element (BeamformerKernels.cu:113,182). */

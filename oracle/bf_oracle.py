@@ -73,6 +73,10 @@ def lib() -> ctypes.CDLL:
         L.dcs_oracle_generate_at.argtypes = [P, c_void_p, c_void_p, Timespec, c_size_t, c_size_t, c_size_t, c_void_p]
         L.dcs_oracle_beamform_dt.argtypes = [P, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]
         L.dcs_oracle_beamform_accumulated.argtypes = [P, c_void_p, c_float, c_size_t, c_void_p, c_void_p]
+        L.dcs_oracle_beamform_accumulated_slab.argtypes = [P, c_void_p, c_float, c_size_t, c_size_t, c_size_t, c_void_p, c_void_p]
+        L.dcs_oracle_beamform_accumulated_slab.restype = None
+        L.dcs_oracle_beamform_slab.argtypes = [P, c_void_p, c_void_p, c_size_t, c_size_t, c_size_t, c_void_p, c_void_p]
+        L.dcs_oracle_beamform_slab.restype = None
         L.dcs_oracle_compare_generated.argtypes = [P, c_void_p, c_void_p, c_size_t, c_size_t, c_size_t, c_void_p, c_int, c_int,
                                                    POINTER(c_uint64 * 4), POINTER(c_uint32), POINTER(c_int64)]
         L.dcs_oracle_compare_generated.restype = c_double
@@ -277,6 +281,36 @@ def beamform_accumulated(p: OracleParams, delays_beam_major: np.ndarray, dt_coef
     out = np.empty((p.nr_channels, nt // 16, p.nr_beams, 16, 2), dtype=np.float32)
     lib().dcs_oracle_beamform_accumulated(byref(p), c_void_p(delays.ctypes.data), float(np.float32(dt_coeff)), nt, c_void_p(ant.ctypes.data),
                                           c_void_p(out.ctypes.data))
+    return out
+
+
+def beamform_slab(p: OracleParams, delays_beam_major: np.ndarray, nt: int, c0: int, nc: int, antenna_slab: np.ndarray, dt=None) -> np.ndarray:
+    """Channels [c0, c0 + nc) of :func:`beamform` (``dt`` None: time indices 0 .. nt-1) / :func:`beamform_dt`."""
+    assert nt % 16 == 0
+    delays = np.ascontiguousarray(delays_beam_major, dtype=delay_vals_dtype)
+    ant = np.ascontiguousarray(antenna_slab, dtype=np.int8)
+    assert ant.size == nc * nt * p.nr_stations * 2 and c0 + nc <= p.nr_channels
+    dtp = c_void_p(None)
+    if dt is not None:
+        dt = np.ascontiguousarray(np.atleast_1d(np.asarray(dt, dtype=np.float32)))
+        assert dt.size == nt
+        dtp = c_void_p(dt.ctypes.data)
+    out = np.empty((nc, nt // 16, p.nr_beams, 16, 2), dtype=np.float32)
+    lib().dcs_oracle_beamform_slab(byref(p), c_void_p(delays.ctypes.data), dtp, nt, int(c0), int(nc), c_void_p(ant.ctypes.data),
+                                   c_void_p(out.ctypes.data))
+    return out
+
+
+def beamform_accumulated_slab(p: OracleParams, delays_beam_major: np.ndarray, dt_coeff: float, nt: int, c0: int, nc: int,
+                              antenna_slab: np.ndarray) -> np.ndarray:
+    """Channels [c0, c0 + nc) of :func:`beamform_accumulated`; ``antenna_slab`` holds those channels only."""
+    assert nt % 16 == 0
+    delays = np.ascontiguousarray(delays_beam_major, dtype=delay_vals_dtype)
+    ant = np.ascontiguousarray(antenna_slab, dtype=np.int8)
+    assert ant.size == nc * nt * p.nr_stations * 2 and c0 + nc <= p.nr_channels
+    out = np.empty((nc, nt // 16, p.nr_beams, 16, 2), dtype=np.float32)
+    lib().dcs_oracle_beamform_accumulated_slab(byref(p), c_void_p(delays.ctypes.data), float(np.float32(dt_coeff)), nt, int(c0), int(nc),
+                                               c_void_p(ant.ctypes.data), c_void_p(out.ctypes.data))
     return out
 
 

@@ -1,9 +1,9 @@
 """ctypes binding of ``include/dcs_probes.h`` (probes/libdcs_probes.so).  Test and measurement
 infrastructure: the product package never imports this.
 
-The probes library also exports the whole ``dcs_bf_*`` API built with ``-DDCS_PROBES``
-(``probe_nomath`` / ``probe_pace`` honoured); to drive it through the ordinary Python wrappers
-start the process with ``DCS_LIB_PATH=probes/libdcs_probes.so``.
+The probes library also exports the whole ``dcs_bf_*`` API built with ``-DDCS_PROBES`` (the measurement knobs of
+``struct dcs_probe_knobs`` honoured: :func:`set_knobs`); to drive it through the ordinary Python wrappers start the
+process with ``DCS_LIB_PATH=probes/libdcs_probes.so``.
 """
 from __future__ import annotations
 
@@ -23,7 +23,12 @@ SIGNATURES = [
     ("dcs_probe_reduce", c_int, [_VP, c_size_t, POINTER(c_uint64), POINTER(c_float), _VP]),
     ("dcs_probe_mfma", c_int, [c_int, c_uint32, c_uint32, _VP, _VP]),
     ("dcs_probe_store_pattern", c_int, [_VP, c_uint32, c_uint32, c_uint32, c_uint32, c_int, c_int, c_int, c_uint32, _VP]),
+    ("dcs_probe_set_knobs", c_int, [_VP, _VP]),
 ]
+
+# struct dcs_probe_knobs (include/dcs_probes.h), in order
+KNOB_FIELDS = ("nomath", "pace", "fail_at_step", "bacc_probe", "bacc_rounds", "bacc_no_share", "bacc_plain", "bacc_wg_per_cu",
+               "bacc_unstaged", "bacc_order")
 
 _LIB = None
 
@@ -87,3 +92,20 @@ def one_store(d_out, nbytes, store_mode, stores_per_thread, row_bytes, stream=No
 
 def mfma(which: int, blocks: int, iters: int, d_out, stream=None) -> None:
     _check(lib().dcs_probe_mfma(int(which), int(blocks), int(iters), c_void_p(int(d_out)), _s(stream)), "dcs_probe_mfma")
+
+
+def set_knobs(gen, **knobs) -> None:
+    """``dcs_probe_set_knobs`` on a :class:`dc_sand_amd.generator.SteeringCoefficientGenerator` whose context was made
+    by THIS library (the process runs with ``DCS_LIB_PATH=probes/libdcs_probes.so``); no keyword = reset."""
+    from dc_sand_amd import _lib as product
+
+    if product.LIB_PATH.resolve() != LIB.resolve():
+        raise RuntimeError("set_knobs needs the probes build behind the wrappers: run with DCS_LIB_PATH=probes/libdcs_probes.so")
+    unknown = set(knobs) - set(KNOB_FIELDS)
+    if unknown:
+        raise TypeError(f"unknown knob(s) {sorted(unknown)}")
+    if not knobs:
+        _check(lib().dcs_probe_set_knobs(c_void_p(gen._h), c_void_p(None)), "dcs_probe_set_knobs")
+        return
+    k = (ctypes.c_int32 * len(KNOB_FIELDS))(*[int(knobs.get(f, 0)) for f in KNOB_FIELDS])
+    _check(lib().dcs_probe_set_knobs(c_void_p(gen._h), ctypes.cast(k, c_void_p)), "dcs_probe_set_knobs")

@@ -70,13 +70,19 @@ def test_single_gpu_line_with_cpu_baseline():
     st = am["streaming_cfg5"]
     assert st["cadence_target_us"] == 200.0 and st["full_tensor_period_us"] > 0
     assert st["largest_slab_at_200us"] is None or st["largest_slab_at_200us"]["period_us"] <= 200.0
+    ev = st["new_table_every_tick"]
+    assert ev["full_tensor_host_table_period_us"] > 0 and ev["full_tensor_device_table_period_us"] > 0
     assert am["fp16_output"]["math_mode"] == 0 and am["fp16_output_b16_arithmetic"]["math_mode"] == 4
     assert am["fused_generate_and_beamform"]["value"] > 0
     ba = am["beamform_accumulated"]
-    assert len(ba) == 2 and all(x["value"] > 0 and 0 < x["frac_of_hbm_peak"] < 1 and x["unit"] == "T coefficient-products/s" for x in ba)
+    assert len(ba) == 3 and all(x["value"] > 0 and 0 < x["frac_of_hbm_peak"] < 1 and x["unit"] == "T coefficient-products/s" for x in ba)
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] == 1 and c["unit"] == "Gcoeff/s" and c["value"] > 0 and c["sample"]
     assert c["gpu_vs_oracle_spot_check"]["over_1ulp"] == 0
+    # every side measurement's last output is checked against the oracle too (in the cpu_baseline leg)
+    xs = c["extras_vs_oracle"]
+    assert len(xs) >= 9 and all(x["ok"] for x in xs), [x for x in xs if not x["ok"]]
+    assert any("device memory" in x["item"] for x in xs) and any(x["item"].startswith("beamform_accumulated 256x") for x in xs)
     assert c["beamform_accumulated"]["value"] > 0 and c["beamform_accumulated"]["cores"] == 1
 
 
@@ -85,6 +91,46 @@ def test_collective_control_flow_over_rccl_world_of_one():
     _common(d)
     assert d["config"]["collective"] == "RCCL broadcast" and d["rccl_world_size"] == 1
     assert "cpu_baseline" not in d
+
+
+def test_gpus_2_without_a_launcher_starts_two_ranks():
+    """The launch contract (bench.py docstring): plain ``python bench.py --gpus 2`` -- the form of the driver's recorded
+    N = 1 command with another N -- starts TWO rank processes itself and relays rank 0's line; it can never print an
+    ``n_gpus: 1`` line for a ``--gpus 2`` request.  Rehearsed with both ranks on GPU 0 over gloo."""
+    d = _run(["--gpus", "2", "--backend", "gloo", "--shared-device", "--check-all-ranks", "--no-cpu-baseline", "--no-extras"])
+    _common(d, n_gpus=2)
+    assert d["n_gpus"] == 2 and len(d["per_rank"]) == 2
+    assert "REHEARSAL" in d["config"]["collective"]
+    assert d["config"]["coeffs_per_step"] == 2 * 16 * 64 * 2048
+
+
+def test_gpus_n_with_fewer_devices_prints_no_line_and_fails():
+    """``--gpus 2`` over RCCL on a ONE-GPU box: rank 1 has no GPU; the command exits non-zero and stdout stays empty."""
+    import torch
+
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("this box has two GPUs")
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    res = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", *SMALL, "--no-cpu-baseline", "--no-extras"],
+                         capture_output=True, text=True, env=env, timeout=600, cwd=str(ROOT))
+    assert res.returncode != 0
+    assert res.stdout.strip() == "", res.stdout[:300]
+    assert "no result line" in res.stderr
+
+
+def test_streaming_step_with_the_table_gathered_in_graph():
+    """``--streaming``: each step is a hipGraph replay fed from the broadcast's device buffer (configs[3] + configs[4]),
+    over RCCL with a world of one rank; the last step is spot-checked against the oracle by every rank."""
+    d = _run(["--force-collective", "--streaming", "--no-cpu-baseline", "--check-all-ranks", "--no-extras"])
+    _common(d)
+    assert "dcs_bf_stream_tick_dt_from_global" in d["config"]["kernel"] and d["rccl_world_size"] == 1
+
+
+def test_named_config_reaches_the_workload_field():
+    d = _run(["--config", "cfg4", "--no-cpu-baseline", "--no-extras"])
+    assert d["config"]["workload"].startswith("cfg4 (shape overridden)") and "configs[3]" in d["config"]["named_config"]
 
 
 def test_two_ranks_sharing_the_gpu_over_gloo():

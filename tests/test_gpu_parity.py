@@ -288,10 +288,9 @@ def test_error_behaviour(gpu):
         with pytest.raises(_lib.DcsError) as e:
             g.set_tuning(**bad)
         assert e.value.status == _lib.DCS_ERR_INVALID_ARGUMENT, bad
-    for probe_only in (dict(probe_pace=3), dict(probe_nomath=True)):  # knobs of libdcs_probes.so (include/dcs_probes.h)
-        with pytest.raises(_lib.DcsError) as e:
+    for probe_only in (dict(probe_pace=3), dict(probe_nomath=True)):  # ABI 2's measurement fields are gone from the struct (ABI 3)
+        with pytest.raises(TypeError):
             g.set_tuning(**probe_only)
-        assert e.value.status == _lib.DCS_ERR_UNSUPPORTED, probe_only
     g.close()
 
 

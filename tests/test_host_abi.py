@@ -29,7 +29,7 @@ def test_header_symbols_are_exported_and_bound(dcs_lib):
         assert hasattr(dcs_lib, name), f"{name} declared in the header but not exported"
         assert name in bound, f"{name} has no ctypes signature in dc_sand_amd/_lib.py"
     assert bound <= set(declared)
-    assert dcs_lib.dcs_abi_version() == 2
+    assert dcs_lib.dcs_abi_version() == 3
 
 
 def test_product_library_exports_no_measurement_apparatus(dcs_lib):
@@ -50,8 +50,47 @@ def test_product_library_exports_no_measurement_apparatus(dcs_lib):
     pexp = {l.split()[-1] for l in psyms.splitlines() if " T " in l}
     text = re.sub(r"/\*.*?\*/", "", (ROOT / "include" / "dcs_probes.h").read_text(), flags=re.S)
     declared_probes = set(re.findall(r"\b(dcs_probe_[a-z0-9_]+)\s*\(", text))
-    assert len(declared_probes) == 7 and declared_probes <= pexp
+    assert len(declared_probes) == 8 and declared_probes <= pexp
+    assert "dcs_probe_set_knobs" in declared_probes and "dcs_probe_set_knobs" not in exported
     assert set(_declared_functions()) <= pexp  # the probes library is a superset build
+
+
+def test_abi_3_structs_as_a_c_compiler_lays_them_out(dcs_lib, tmp_path):
+    """ABI 3: ``struct dcs_bf_tuning`` is ten int32_t with NO measurement field (ABI 2 had ``probe_nomath`` /
+    ``probe_pace``; they are ``struct dcs_probe_knobs`` of include/dcs_probes.h now), in the order the Python wrapper
+    fills them; ``struct dcs_bf_params`` and ``struct dcs_delay_vals`` as the reference header has them.  Layout taken
+    from gcc compiling the public header as plain C, not from this file's idea of it."""
+    import subprocess
+
+    from dc_sand_amd.generator import SteeringCoefficientGenerator
+    from probes.dcs_probes import KNOB_FIELDS
+
+    hdr = (ROOT / "include" / "dcs_beamformer.h").read_text()
+    body = re.search(r"struct dcs_bf_tuning \{(.*?)\n\};", hdr, re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = re.findall(r"int32_t\s+([a-z_0-9]+);", body)
+    assert tuple(fields) == SteeringCoefficientGenerator.TUNING_FIELDS and len(fields) == 10
+    assert not any("probe" in f for f in fields) and "must be 0" not in hdr
+    pbody = re.search(r"struct dcs_probe_knobs \{(.*?)\n\};", (ROOT / "include" / "dcs_probes.h").read_text(), re.S).group(1)
+    pfields = re.findall(r"int32_t\s+([a-z_0-9]+);", re.sub(r"/\*.*?\*/", "", pbody, flags=re.S))
+    assert tuple(pfields) == KNOB_FIELDS
+    src = tmp_path / "layout.c"
+    src.write_text(
+        '#include <stdio.h>\n#include <stddef.h>\n#include "dcs_probes.h"\n'
+        "int main(void) {\n"
+        '  printf("%zu %zu %zu %zu\\n", sizeof(struct dcs_bf_tuning), sizeof(struct dcs_bf_params), sizeof(struct dcs_delay_vals), sizeof(struct dcs_probe_knobs));\n'
+        + "".join(f'  printf("{f} %zu\\n", offsetof(struct dcs_bf_tuning, {f}));\n' for f in fields)
+        + '  printf("abi %d\\n", DCS_BF_ABI_VERSION);\n  return 0;\n}\n'
+    )
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-std=gnu11", "-Wall", "-Werror", "-I", str(ROOT / "include"), str(src), "-o", str(exe)], check=True,
+                   capture_output=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split("\n")
+    assert out[0] == f"40 40 16 {4 * len(KNOB_FIELDS)}"
+    assert [l.split() for l in out[1:11]] == [[f, str(4 * i)] for i, f in enumerate(fields)]
+    assert out[11] == "abi 3"
+    # 49 entry points in ABI 2 + the three device-table stream ticks
+    assert len(_declared_functions()) == 52
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):

@@ -20,7 +20,7 @@ the tests use.  The store-only studies need the probes build (include/dcs_probes
     python tools/measure.py sustained [--seconds 6]
         back-to-back launches at config 3 for several seconds (rate per second)
     DCS_LIB_PATH=probes/libdcs_probes.so python tools/measure.py stores --kind pattern|lean|kernel ...
-        store-only probes and the real kernel with probe_nomath / probe_pace        -> profiles/r01_store_patterns.md
+        store-only probes and the real kernel with dcs_probe_knobs nomath / pace        -> profiles/r01_store_patterns.md
     python tools/measure.py sincos
         device sweep of the sincos forms over every fp32 in [1, 128)                 -> profiles/r01_sincos_ab.md
 """
@@ -388,7 +388,8 @@ def cmd_stores(args):
         for cpb in [int(v) for v in args.cpb.split(",")]:
             for pace in [int(v) for v in args.pace.split(",")]:
                 for nomath in (False, True):
-                    g.set_tuning(form=1, tiles_per_block=1, chan_per_block=cpb, nontemporal=1, probe_pace=pace, probe_nomath=nomath)
+                    g.set_tuning(form=1, tiles_per_block=1, chan_per_block=cpb, nontemporal=1)
+                    pr.set_knobs(g, pace=pace, nomath=int(nomath))  # include/dcs_probes.h (the probes build behind the wrappers)
                     ms = per_launch_ms(lambda: g.generate(buf, nbytes, t0=1, nt=1))
                     print(f"kernel cpb={cpb} pace={pace} nomath={int(nomath)}: {nbytes / ms / 1e9:.2f} TB/s", flush=True)
         g.close()
