@@ -46,6 +46,20 @@
 
 namespace {
 
+// Workgroup numbering, XCD-aware.  The hardware hands workgroup w to XCD w % 8, and every XCD has its own L2.  The
+// logical order below is beam group fastest, then sample-block group, then channel: the n_bgroups workgroups that read
+// the SAME samples (one channel's blocks) are neighbours in it.  Numbered as dispatched, those neighbours landed on
+// n_bgroups different XCDs and each L2 fetched the samples again (FETCH_SIZE 4.0 x the algorithmic input at 64 x 256
+// beams, profiles/r02_fused.md).  So the dispatch number is turned into a logical one that gives every XCD ONE
+// CONTIGUOUS RANGE of the logical order: XCD x takes [base(x), base(x) + count(x)), its q-th workgroup the q-th of
+// them -- the sharers now follow each other on one XCD and all but the first hit its L2.  A bijection for any grid
+// size (count(x) = T / 8 + (x < T % 8)).
+__device__ __forceinline__ uint32_t xcd_contiguous(uint32_t bid, uint32_t total)
+{
+    const uint32_t per = total >> 3, rem = total & 7u, x = bid & 7u, q = bid >> 3;
+    return x * per + min(x, rem) + q;
+}
+
 constexpr uint32_t kKC = 64; // antennas per staged chunk (16 k-steps of 4)
 
 template <int NBT>
@@ -57,7 +71,7 @@ __global__ void __launch_bounds__(kBlock) bf_beamform_acc_kernel(const bf_bacc_a
     extern __shared__ __attribute__((aligned(16))) float lds[];   // Wre[A_pad][WS] | Wim[A_pad][WS]
     const uint32_t A_pad = (a.A + 3u) & ~3u;
 
-    uint32_t bid = blockIdx.x;
+    uint32_t bid = BACC_KNOB(a, order) == 1u ? blockIdx.x : xcd_contiguous(blockIdx.x, gridDim.x);
     const uint32_t bg = bid % a.n_bgroups;
     bid /= a.n_bgroups;
     const uint32_t tg = bid % a.n_tgroups;
@@ -243,7 +257,7 @@ bf_beamform_i8_kernel(const bf_bacc_args a)
 {
     constexpr bool STAGED = FORM == kStaged, SPLIT = FORM == kSplit;
     extern __shared__ __attribute__((aligned(16))) char staged[]; // kStaged: the sample image (+ the coefficient exchange); kSplit: the partial sums
-    uint32_t bid = blockIdx.x;
+    uint32_t bid = BACC_KNOB(a, order) == 1u ? blockIdx.x : xcd_contiguous(blockIdx.x, gridDim.x);
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t bg = bid % a.n_bgroups;
