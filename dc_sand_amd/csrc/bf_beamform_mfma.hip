@@ -47,18 +47,43 @@
 namespace {
 
 // Workgroup numbering, XCD-aware.  The hardware hands workgroup w to XCD w % 8, and every XCD has its own L2.  The
-// logical order below is beam group fastest, then sample-block group, then channel: the n_bgroups workgroups that read
-// the SAME samples (one channel's blocks) are neighbours in it.  Numbered as dispatched, those neighbours landed on
-// n_bgroups different XCDs and each L2 fetched the samples again (FETCH_SIZE 4.0 x the algorithmic input at 64 x 256
-// beams, profiles/r02_fused.md).  So the dispatch number is turned into a logical one that gives every XCD ONE
-// CONTIGUOUS RANGE of the logical order: XCD x takes [base(x), base(x) + count(x)), its q-th workgroup the q-th of
-// them -- the sharers now follow each other on one XCD and all but the first hit its L2.  A bijection for any grid
-// size (count(x) = T / 8 + (x < T % 8)).
-__device__ __forceinline__ uint32_t xcd_contiguous(uint32_t bid, uint32_t total)
+// logical order below is beam group fastest, then sample-block group, then channel: the n_bgroups workgroups that
+// read the SAME samples (one channel's blocks) are neighbours in it.  Numbered as dispatched, those neighbours land on
+// different XCDs and each L2 fetches the samples again (FETCH_SIZE 4.0 x the algorithmic input at 64 x 256 beams,
+// profiles/r02_fused.md -- served by the 256 MiB Infinity Cache behind the L2s, not by HBM, as it turned out).  With
+// G = a.xcd_group > 1 the dispatch number w (XCD x = w % 8, that XCD's q-th workgroup, q = w / 8) becomes the logical
+// number of member q % G of sharer group (q / G) * 8 + x: the G sharers follow each other on ONE XCD -- all but the
+// first hit its L2 (FETCH_SIZE 1.04 x) -- while the eight XCDs still work on eight NEIGHBOURING groups at any moment.
+// (Giving every XCD one contiguous eighth of the order instead keeps the sharers together just as well, but sends the
+// XCDs to eight far-apart address windows: 6 % slower where there is nothing to share.)  A bijection: on the whole
+// multiples of 8 G by construction, identity on the tail; identity altogether for G = 1.  The launcher decides G from
+// measurements (profiles/r03_fused.md): the sharers' count for the forms of more than 64 antennas (each workgroup reads
+// 4 x what it writes: -18 % time), and for the staged form from 16 sharers on (+3.5 %; at 2 - 8 sharers the grouped
+// order measured 1.5 - 7 % SLOWER -- four workgroups missing on the same lines of one L2 at the same moment -- so those
+// stay as dispatched).
+__device__ __forceinline__ uint32_t xcd_grouped(uint32_t w, uint32_t total, uint32_t G)
 {
-    const uint32_t per = total >> 3, rem = total & 7u, x = bid & 7u, q = bid >> 3;
-    return x * per + min(x, rem) + q;
+    const uint32_t full = total - total % (8u * G);
+    if (G <= 1u || w >= full) return w;
+    const uint32_t x = w & 7u, q = w >> 3;
+    return ((q / G) * 8u + x) * G + q % G;
 }
+#ifdef DCS_PROBES
+// A/B of the numbering (dcs_probe_knobs.bacc_order): 0 = the launcher's choice, 1 = as dispatched (round 2), 2 = one
+// contiguous eighth of the order per XCD, 3 = sharers grouped whatever their number
+__device__ __forceinline__ uint32_t probe_order(uint32_t order, uint32_t w, uint32_t total, uint32_t G, uint32_t n_sharers)
+{
+    if (order == 1u) return w;
+    if (order == 2u) {
+        const uint32_t per = total >> 3, rem = total & 7u, x = w & 7u, q = w >> 3;
+        return x * per + min(x, rem) + q;
+    }
+    return xcd_grouped(w, total, order == 3u ? n_sharers : G);
+}
+#define BACC_LOGICAL_ID(a) probe_order((a).order, blockIdx.x, gridDim.x, (a).xcd_group, (a).n_bgroups)
+#else
+#define BACC_LOGICAL_ID(a) xcd_grouped(blockIdx.x, gridDim.x, (a).xcd_group)
+#endif
 
 constexpr uint32_t kKC = 64; // antennas per staged chunk (16 k-steps of 4)
 
@@ -71,7 +96,7 @@ __global__ void __launch_bounds__(kBlock) bf_beamform_acc_kernel(const bf_bacc_a
     extern __shared__ __attribute__((aligned(16))) float lds[];   // Wre[A_pad][WS] | Wim[A_pad][WS]
     const uint32_t A_pad = (a.A + 3u) & ~3u;
 
-    uint32_t bid = BACC_KNOB(a, order) == 1u ? blockIdx.x : xcd_contiguous(blockIdx.x, gridDim.x);
+    uint32_t bid = BACC_LOGICAL_ID(a);
     const uint32_t bg = bid % a.n_bgroups;
     bid /= a.n_bgroups;
     const uint32_t tg = bid % a.n_tgroups;
@@ -248,16 +273,30 @@ __device__ __forceinline__ uint32_t fixed_word(float w)
 //       96 in one wave), loads that chunk's operands itself, and the four partial sums of a pair of blocks meet in
 //       LDS: each wave adds up, scales and stores the four beams of one result register (wave w: beams w, w + 4 ... of
 //       the tile).  Two barriers per trip of two pairs.
+//   kChain  (64 < nr_stations <= 256; the product's form there since round 3): the workgroup owns ONE beam tile and its
+//       coefficients -- wave w makes those of antennas [64 w, 64 w + 64), as in kSplit -- go to LDS (4 chunks x 6 operands x
+//       1 KiB = 24 KiB), from where EVERY wave reads them (one ds_read_b128 per operand and chunk).  Wave w then takes the
+//       sample blocks w, w + 4, ... by itself and walks ALL the antenna chunks of a pair of blocks with the matrix
+//       instruction's own accumulator: the twelve integer sums (3 digits x 4 planes) run through the chunks in int32,
+//       exactly (|sum| <= 128 * 128 * 256 = 2^22), and are recombined ONCE per pair.  Against kSplit: no partial sums in
+//       LDS, no barrier inside the loop (kSplit: two per trip, every wave waiting for the slowest), a quarter of the
+//       recombination arithmetic, and a result that is one fp32 rounding closer to the exact sum.
 // FULL: nr_stations is a multiple of 64 (no antenna masks, immediate load offsets).
-enum { kStaged = 0, kDirect = 1, kSplit = 2 };
+enum { kStaged = 0, kDirect = 1, kSplit = 2, kChain = 3 };
+#ifndef DCS_CHAIN_DEPTH
+#define DCS_CHAIN_DEPTH 2 // sample buffers of the kChain walk: the samples of step s + DEPTH - 1 are requested while step s is worked on
+#endif
+#ifndef DCS_CHAIN_WAVES
+#define DCS_CHAIN_WAVES 3 // waves per SIMD the kChain form is allocated for (147 VGPRs; 4 would need <= 128: measured, profiles/r03_fused.md)
+#endif
 
 template <int FORM, bool FULL>
-__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(FORM == kSplit ? (FULL ? 3 : 2) : (FULL || FORM == kStaged ? 4 : 3))))
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(FORM == kSplit ? (FULL ? 3 : 2) : (FORM == kChain ? DCS_CHAIN_WAVES : (FULL || FORM == kStaged ? 4 : 3)))))
 bf_beamform_i8_kernel(const bf_bacc_args a)
 {
-    constexpr bool STAGED = FORM == kStaged, SPLIT = FORM == kSplit;
+    constexpr bool STAGED = FORM == kStaged, SPLIT = FORM == kSplit, CHAIN = FORM == kChain;
     extern __shared__ __attribute__((aligned(16))) char staged[]; // kStaged: the sample image (+ the coefficient exchange); kSplit: the partial sums
-    uint32_t bid = BACC_KNOB(a, order) == 1u ? blockIdx.x : xcd_contiguous(blockIdx.x, gridDim.x);
+    uint32_t bid = BACC_LOGICAL_ID(a);
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t bg = bid % a.n_bgroups;
@@ -265,18 +304,18 @@ bf_beamform_i8_kernel(const bf_bacc_args a)
     const uint32_t tg = bid % a.n_tgroups;
     const uint32_t c = bid / a.n_tgroups;
     // beam tiles per workgroup, sample blocks per round (kSplit: one tile, every wave takes every block)
-    const uint32_t nbt_log2 = SPLIT ? 0u : a.nbt_log2;
+    const uint32_t nbt_log2 = SPLIT || CHAIN ? 0u : a.nbt_log2;
     const uint32_t nbt = 1u << nbt_log2, tpr = SPLIT ? 1u : 4u >> nbt_log2;
     const uint32_t bt = SPLIT ? 0u : wave & (nbt - 1u), slot = SPLIT ? 0u : wave >> nbt_log2;
-    const uint32_t kc = SPLIT ? wave : 0u;         // this wave's 64-antenna chunk
+    const uint32_t kc = SPLIT || CHAIN ? wave : 0u; // the 64-antenna chunk whose coefficients this wave makes (and, kSplit, contracts)
     const uint32_t lm = lane & 15u, lg = lane >> 4;
     const uint32_t bw = (bg * nbt + bt) * 16u;     // first beam of this wave's tile
     const uint32_t tt0 = tg * a.tiles_per_wg;      // first 16-sample block of the workgroup
     const uint32_t tt1 = min(tt0 + a.tiles_per_wg, a.nT16);
     const uint32_t n_blocks = tt1 > tt0 + slot ? (tt1 - tt0 - slot + tpr - 1u) / tpr : 0u; // this wave's sample blocks
     const bool idle = bw >= a.B || n_blocks == 0u; // wave-uniform (kSplit: workgroup-uniform)
-    if (!STAGED && idle) return;                   // (no barrier behind this in the direct form; all waves alike in kSplit)
-    const bool has_chunk = !SPLIT || 64u * kc < a.A; // kSplit with <= 192 antennas: the last wave(s) only add and store
+    if (!STAGED && !CHAIN && idle) return;         // (no barrier behind this in the direct form; all waves alike in kSplit)
+    const bool has_chunk = !(SPLIT || CHAIN) || 64u * kc < a.A; // kSplit / kChain with <= 192 antennas: the last wave(s) have no chunk of their own
     if (STAGED) { // this wave's share of the workgroup's blocks: global -> LDS, 1 KiB per instruction, same byte order
         typedef __attribute__((address_space(3))) void lds_void;
         typedef const __attribute__((address_space(1))) void glb_void;
@@ -411,13 +450,13 @@ bf_beamform_i8_kernel(const bf_bacc_args a)
     const bool second = lm >= 8u;                    // this lane's columns belong to block B of the pair
     const uint32_t last = n_blocks - 1u;
     const uint32_t voff = lg * 32u + m * 4u;
-    uint32_t cur[2][16];
+    uint32_t cur[CHAIN ? DCS_CHAIN_DEPTH : 2][16];
     // "every loaded register is needed HERE": keeps the compiler from sinking a load set into the trip that consumes it
     auto arrived = [&](uint32_t (&v)[16]) {
         asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]));
         asm volatile("" : "+v"(v[8]), "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15]));
     };
-    auto fetch = [&](uint32_t (&dst)[16], uint32_t blk) { // pair (blk, min(blk + 1, last)), this wave's chunk
+    auto fetch = [&](uint32_t (&dst)[16], uint32_t blk, uint32_t kc) { // pair (blk, min(blk + 1, last)), antenna chunk kc
         const uint32_t blkA = min(blk, last), blkB = min(blk + 1u, last);
         if (STAGED) { // from the LDS image: block j of the workgroup at j * blk_bytes
             const uint32_t at = ((second ? blkB : blkA) * tpr + slot) * blk_bytes + m * 4u;
@@ -553,8 +592,8 @@ bf_beamform_i8_kernel(const bf_bacc_args a)
                     finish(whole, blk + 2u * h, f);
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                fetch(cur[0], blk + 4u);
-                fetch(cur[1], blk + 6u);
+                fetch(cur[0], blk + 4u, kc);
+                fetch(cur[1], blk + 6u, kc);
             }
             return;
         }
@@ -563,7 +602,7 @@ bf_beamform_i8_kernel(const bf_bacc_args a)
             for (uint32_t blk = 0; blk < n_blocks; blk += 2) {
                 intx4 x[4];
                 floatx4 f[4];
-                fetch(cur[0], blk);
+                fetch(cur[0], blk, 0u);
                 transpose(cur[0], x);
                 contract(x, f);
                 finish(whole, blk, f);
@@ -593,14 +632,15 @@ bf_beamform_i8_kernel(const bf_bacc_args a)
                 }
                 __builtin_amdgcn_sched_barrier(0); // the loads stay behind the stores (see above)
                 if (has_chunk) {
-                    fetch(cur[0], blk + 4u);
-                    fetch(cur[1], blk + 6u);
+                    fetch(cur[0], blk + 4u, kc);
+                    fetch(cur[1], blk + 6u, kc);
                 }
             }
         }
     };
     // the first trip's samples (kStaged: all of them, above) travel while the coefficients are made
-    if (!STAGED && has_chunk) fetch(cur[0], 0);
+    if (!STAGED && !CHAIN && has_chunk) fetch(cur[0], 0, kc);
+    if (CHAIN && !idle) fetch(cur[0], 0, 0u); // the first (pair, chunk) of this wave's own blocks
     __builtin_amdgcn_sched_barrier(0);
 #ifdef DCS_PROBES
     if (a.probe == 3u || a.probe == 4u) { // no coefficients either: the store pattern alone
@@ -608,13 +648,13 @@ bf_beamform_i8_kernel(const bf_bacc_args a)
         for (int d = 0; d < 3; d++) wre[d] = wim[d] = intx4{(int)lane, d, 2, 1};
     } else
 #endif
-    if ((shared_w ? bw < a.B : !idle) && has_chunk) make_coefficients();
+    if ((shared_w || CHAIN ? bw < a.B : !idle) && has_chunk) make_coefficients(); // (kChain: a wave without blocks still makes its chunk)
     if (cls == DCS_CLASS_SLOW) { // bit i: result row i (lanes i, i + 16, i + 32, i + 48 hold its antennas) has a non-finite coefficient
         const uint64_t br = __builtin_amdgcn_ballot_w64(bad_re), bi = __builtin_amdgcn_ballot_w64(bad_im);
         nan_re = (uint32_t)((br | (br >> 16) | (br >> 32) | (br >> 48)) & 0xffffu);
         nan_im = (uint32_t)((bi | (bi >> 16) | (bi >> 32) | (bi >> 48)) & 0xffffu);
     }
-    if (STAGED) {
+    if constexpr (STAGED) {
         uint32_t *wx = reinterpret_cast<uint32_t *>(staged + a.share_off) + bt * (4u * 6u * 64u) + lane; // [tile][q][plane][lane]
         if (shared_w && bw < a.B) {
 #pragma unroll
@@ -634,8 +674,88 @@ bf_beamform_i8_kernel(const bf_bacc_args a)
                     for (int d = 0; d < 3; d++) wre[d][q] = (int)wx[(q * 6u + d) * 64u], wim[d][q] = (int)wx[(q * 6u + 3u + d) * 64u];
                 }
         }
+    } else if constexpr (CHAIN) {
+        // ---- the coefficients of this wave's chunk to LDS: [chunk][operand: re d1, d2, d3, im d1, d2, d3][lane] x 16 bytes
+        intx4 *coef = reinterpret_cast<intx4 *>(staged);
+        uint32_t *nanw = reinterpret_cast<uint32_t *>(staged + 4u * 6u * 64u * 16u); // [chunk][re, im]
+        if (has_chunk) {
+#pragma unroll
+            for (int d = 0; d < 3; d++) coef[(kc * 6u + (uint32_t)d) * 64u + lane] = wre[d], coef[(kc * 6u + 3u + (uint32_t)d) * 64u + lane] = wim[d];
+        }
+        if (lane == 0u) nanw[2u * wave] = has_chunk ? nan_re : 0u, nanw[2u * wave + 1u] = has_chunk ? nan_im : 0u;
+        __syncthreads(); // the kernel's only barrier
+        if (idle) return;
+#if DCS_CHAIN_DEPTH == 3
+        {
+            const uint32_t nch = (a.A + 63u) / 64u; // step 1 of this wave: (pair 0, chunk 1), or (pair 1, chunk 0) of a one-chunk problem
+            if (nch * ((n_blocks + 1u) >> 1) > 1u) fetch(cur[1], nch > 1u ? 0u : 2u, nch > 1u ? 1u : 0u);
+        }
+#endif
+        nan_re = nanw[0] | nanw[2] | nanw[4] | nanw[6]; // a non-finite coefficient in ANY chunk poisons the row
+        nan_im = nanw[1] | nanw[3] | nanw[5] | nanw[7];
+        const uint32_t n_chunks = (a.A + 63u) / 64u;
+        auto run_chain = [&](auto whole) {
+            // a step = (pair of this wave's blocks, antenna chunk), pair-major; DCS_CHAIN_DEPTH sample buffers in rotation: the
+            // samples of step s + DEPTH - 1 are requested before step s is worked on (steps 0 .. DEPTH - 2 were requested
+            // around the coefficient making)
+            const uint32_t n_steps = ((n_blocks + 1u) >> 1) * n_chunks;
+            intx4 acc[4][3];
+            uint32_t s = 0, chunk = 0, blk = 0;
+            uint32_t f_s = DCS_CHAIN_DEPTH - 1u, f_chunk = (DCS_CHAIN_DEPTH - 1u) % n_chunks, f_blk = 2u * ((DCS_CHAIN_DEPTH - 1u) / n_chunks); // next step to request
+            auto step = [&](uint32_t (&now)[16], uint32_t (&ahead)[16]) {
+                arrived(now);
+                if (f_s < n_steps) fetch(ahead, f_blk, f_chunk);
+                f_s++;
+                if (++f_chunk == n_chunks) f_chunk = 0u, f_blk += 2u;
+                intx4 x[4];
+                transpose(now, x);
+                if (chunk == 0u) {
+#pragma unroll
+                    for (int v = 0; v < 4; v++)
+#pragma unroll
+                        for (int d = 0; d < 3; d++) acc[v][d] = zero;
+                }
+#pragma unroll
+                for (int half = 0; half < 2; half++) { // re planes (v = 0, 2), then im planes (v = 1, 3)
+                    intx4 w[3];
+#pragma unroll
+                    for (int d = 0; d < 3; d++) w[d] = coef[(chunk * 6u + 3u * (uint32_t)half + (uint32_t)d) * 64u + lane];
+#pragma unroll
+                    for (int v = half; v < 4; v += 2)
+#pragma unroll
+                        for (int d = 0; d < 3; d++) acc[v][d] = __builtin_amdgcn_mfma_i32_16x16x64_i8(w[d], x[v], acc[v][d], 0, 0, 0);
+                }
+                if (chunk + 1u == n_chunks) { // all antennas in: digits d1 = acc[v][0], d2 = acc[v][1], d3 = acc[v][2]
+                    floatx4 f[4];
+#pragma unroll
+                    for (int v = 0; v < 4; v++)
+#pragma unroll
+                        for (int r = 0; r < 4; r++) f[v][r] = fmaf((float)acc[v][0][r], 65536.0f, (float)(acc[v][1][r] * 256 + acc[v][2][r]));
+                    finish(whole, blk, f);
+                    chunk = 0u, blk += 2u;
+                } else {
+                    chunk++;
+                }
+                s++;
+            };
+            while (s < n_steps) {
+#if DCS_CHAIN_DEPTH == 3
+                step(cur[0], cur[2]);
+                if (s < n_steps) step(cur[1], cur[0]);
+                if (s < n_steps) step(cur[2], cur[1]);
+#else
+                step(cur[0], cur[1]);
+                if (s < n_steps) step(cur[1], cur[0]);
+#endif
+            }
+        };
+        if (bw + 16u <= a.B)
+            run_chain(std::true_type{});
+        else
+            run_chain(std::false_type{});
+        return;
     } else if (has_chunk) {
-        fetch(cur[1], 2);
+        fetch(cur[1], 2, kc);
     }
     if (bw + 16u <= a.B)
         run(std::true_type{});
@@ -668,8 +788,10 @@ hipError_t bf_launch_beamform_acc(const bf_bacc_args &a_in, hipStream_t stream)
     const bool chain = a.fp32_chain != 0u;
     // beam tiles per workgroup: as many as the beams need; the fp32 form keeps its coefficient planes in LDS and
     // takes as many as still admit 6 workgroups per CU (26 KiB each), one tile whatever it takes beyond
-    const bool split = !chain && a.A > 64u; // the int8 form's K-split: one beam tile per workgroup, a 64-antenna chunk per wave
-    int nbt = split ? 1 : (a.B > 32u ? 4 : (a.B > 16u ? 2 : 1));
+    // more than 64 antennas, int8 form: one beam tile per workgroup; kChain (the product's form) or, probes build only, kSplit
+    const bool wide = !chain && a.A > 64u;
+    const bool split = wide && BACC_KNOB(a, unstaged) != 0u; // kSplit (round 2): every wave takes every block, partial sums meet in LDS
+    int nbt = wide ? 1 : (a.B > 32u ? 4 : (a.B > 16u ? 2 : 1));
     while (chain && nbt > 1 && bacc_lds_bytes(nbt, a.A) > 26u * 1024u) nbt >>= 1;
     const size_t lds = chain ? bacc_lds_bytes(nbt, a.A) : 0u;
     a.nbt_log2 = nbt == 4 ? 2u : (nbt == 2 ? 1u : 0u);
@@ -679,7 +801,7 @@ hipError_t bf_launch_beamform_acc(const bf_bacc_args &a_in, hipStream_t stream)
     // chip idle behind the last ones), fewer while that leaves the chip under 4096 workgroups
     const uint32_t tpr = split ? 1u : 4u / (uint32_t)nbt; // (K-split: every wave takes every block)
     const bool staged_form = !chain && a.A <= 64u && !BACC_KNOB(a, unstaged); // at most 16 blocks (32 KiB of LDS) per workgroup
-    const uint32_t max_rounds = BACC_KNOB(a, max_rounds) ? BACC_KNOB(a, max_rounds) : (chain ? 16u : (staged_form || split ? 16u / tpr : 32u));
+    const uint32_t max_rounds = BACC_KNOB(a, max_rounds) ? BACC_KNOB(a, max_rounds) : (chain ? 16u : (staged_form || wide ? 16u / tpr : 32u));
     uint32_t tiles = (a.nT16 + tpr - 1u) / tpr * tpr;
     if (tiles > max_rounds * tpr) { // several workgroups per (channel, beam group): equal shares (17 blocks are 9 + 8, not 16 + 1)
         const uint32_t parts = (a.nT16 + max_rounds * tpr - 1u) / (max_rounds * tpr);
@@ -691,6 +813,8 @@ hipError_t bf_launch_beamform_acc(const bf_bacc_args &a_in, hipStream_t stream)
     while (tiles > tpr && (uint64_t)a.C * a.n_bgroups * ((a.nT16 + tiles - 1u) / tiles) < enough) tiles = ((tiles / tpr + 1u) / 2u) * tpr;
     a.tiles_per_wg = tiles;
     a.n_tgroups = (a.nT16 + tiles - 1u) / tiles;
+    // the workgroups that share a channel's samples on one XCD? (xcd_grouped above; measured)
+    a.xcd_group = wide ? a.n_bgroups : (!chain && a.n_bgroups >= 16u ? a.n_bgroups : 1u);
     const uint64_t blocks = (uint64_t)a.C * a.n_bgroups * a.n_tgroups;
     if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
     const dim3 grid((uint32_t)blocks), block(kBlock);
@@ -722,12 +846,20 @@ hipError_t bf_launch_beamform_acc(const bf_bacc_args &a_in, hipStream_t stream)
         else
             hipLaunchKernelGGL((bf_beamform_i8_kernel<kDirect, false>), grid, block, 0, stream, a);
 #endif
-    } else { // 2 pairs x 4 registers x 4 chunks x 64 lanes x 16 bytes of partial sums
+#ifdef DCS_PROBES
+    } else if (split) { // 2 pairs x 4 registers x 4 chunks x 64 lanes x 16 bytes of partial sums
         const size_t part_bytes = 2u * 4u * 4u * 64u * 16u;
         if (a.A % 64u == 0u)
             hipLaunchKernelGGL((bf_beamform_i8_kernel<kSplit, true>), grid, block, part_bytes, stream, a);
         else
             hipLaunchKernelGGL((bf_beamform_i8_kernel<kSplit, false>), grid, block, part_bytes, stream, a);
+#endif
+    } else { // kChain: 4 chunks x 6 operands x 64 lanes x 16 bytes of coefficients + the chunks' NaN-row words
+        const size_t coef_bytes = 4u * 6u * 64u * 16u + 8u * sizeof(uint32_t);
+        if (a.A % 64u == 0u)
+            hipLaunchKernelGGL((bf_beamform_i8_kernel<kChain, true>), grid, block, coef_bytes, stream, a);
+        else
+            hipLaunchKernelGGL((bf_beamform_i8_kernel<kChain, false>), grid, block, coef_bytes, stream, a);
     }
     return hipGetLastError();
 }

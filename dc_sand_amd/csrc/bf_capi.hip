@@ -125,12 +125,13 @@ struct dcs_bf_context {
     float *d_tt_terms;      // [kTermsInline][pairs_pad][2]
     uint32_t *d_tt_flags;   // [kTermsInline][pairs_pad/64]
     dcs_bf_tuning tune;     // the caller's explicit knobs (dcs_bf_set_tuning); 0 / -1 = not set
-    // what dcs_bf_autotune measured for this context's shape, per output width [0] = fp32, [1] = fp16;
+    // what dcs_bf_autotune measured for this context's shape, per kernel family: [0] = fp32, [1] = fp16 from the
+    // fp32-grade arithmetic, [2] = fp16 from the b16 arithmetic form (math_mode bit 2: another kernel, another optimum);
     // used for large launches wherever the caller has not set a knob explicitly
     struct tuned_geom {
         bool valid;
         int32_t tpb, cpb, wpc; // wpc: -1 = unlimited
-    } tuned[2];
+    } tuned[3];
 #ifdef DCS_PROBES
     dcs_probe_knobs probe;  // measurement knobs (include/dcs_probes.h); the product build has no such member
 #endif
@@ -496,7 +497,7 @@ int dcs_bf_set_tuning(dcs_bf_context *c, const dcs_bf_tuning *t)
         c->k.uDiv3Exact = c->div3_verified;
         c->k.fLowDegLimit = 500.0f;
         c->k.uHalfMath = 0u;
-        c->tuned[0].valid = c->tuned[1].valid = false; // forget what dcs_bf_autotune measured, too
+        c->tuned[0].valid = c->tuned[1].valid = c->tuned[2].valid = false; // forget what dcs_bf_autotune measured, too
         return DCS_OK;
     }
     if (t->form < 0 || t->form > 3) return DCS_ERR_INVALID_ARGUMENT;
@@ -598,8 +599,12 @@ bf_geom shape_default_geometry(const dcs_bf_context *c, bool out16, uint32_t nc,
     if (want_terms_table(c, out16, g, nc, nt)) {
         g.tpb = 1;
         if (out16) {
-            g.cpb = half ? 32u : 64u;
-            g.wpc = half ? 6 : 0;
+            // b16 arithmetic form (VALU-issue- and power-bound at 21 operations per coefficient): what decides is the number
+            // of channel rows the resident workgroups hold open, chan_per_block x workgroups per CU -- 96-120 rows (24-30 MiB
+            // of output) is the ridge on every box swept, 140-190 falls off a cliff whose position moves between boxes
+            // (profiles/r03_fp16.md): 24 channels x 5 workgroups per CU
+            g.cpb = half ? 24u : 64u;
+            g.wpc = half ? 5 : 0;
         } else {
             g.cpb = 8u;
             g.wpc = 6;
@@ -624,11 +629,13 @@ bf_geom shape_default_geometry(const dcs_bf_context *c, bool out16, uint32_t nc,
     return g;
 }
 
+int tuned_slot(const dcs_bf_context *c, bool out16) { return out16 ? (c->k.uHalfMath != 0u ? 2 : 1) : 0; }
+
 bf_geom pick_geometry(const dcs_bf_context *c, bool out16, uint32_t nc, uint32_t nt)
 {
     constexpr uint64_t kResident = 256u * 8u;
     bf_geom g = shape_default_geometry(c, out16, nc, nt);
-    const dcs_bf_context::tuned_geom &t = c->tuned[out16 ? 1 : 0];
+    const dcs_bf_context::tuned_geom &t = c->tuned[tuned_slot(c, out16)];
     if (t.valid && tiled_blocks(c->n_pairs, out16, t.tpb, (uint32_t)t.cpb, nc, nt) > kResident) {
         g.tpb = t.tpb;
         g.cpb = (uint32_t)t.cpb;
@@ -1238,7 +1245,7 @@ int dcs_bf_autotune(dcs_bf_context *c, int bitwidth, void *d_out, size_t out_byt
         const int cap = refuse_if_capturing(s); // the tuner blocks on events
         if (cap != DCS_OK) return cap;
     }
-    dcs_bf_context::tuned_geom &slot = c->tuned[out16 ? 1 : 0];
+    dcs_bf_context::tuned_geom &slot = c->tuned[tuned_slot(c, out16)];
 
     auto report = [&]() {
         if (!chosen) return;
@@ -1263,7 +1270,10 @@ int dcs_bf_autotune(dcs_bf_context *c, int bitwidth, void *d_out, size_t out_byt
                                  {1, 14, 6}, {1, 8, 5}, {1, 9, 5}, {1, 10, 5}, {1, 11, 5}, {1, 12, 5}, {1, 14, 5}, {1, 16, 5}, {2, 6, -1}, {2, 8, -1}};
     static const int k16[][3] = {{1, 16, -1}, {1, 24, -1}, {1, 32, -1}, {1, 48, -1}, {1, 64, -1}, {1, 96, -1}, {1, 128, -1},
                                  {1, 192, -1}, {1, 256, -1}, {1, 24, 6}, {1, 32, 6}, {1, 48, 6}, {1, 64, 6}, {1, 32, 7},
-                                 {1, 64, 7}, {1, 128, 7}, {2, 32, -1}, {2, 64, -1}};
+                                 {1, 64, 7}, {1, 128, 7}, {2, 32, -1}, {2, 64, -1},
+                                 // the short walks under a residency cap the b16 arithmetic form peaks at (24-30 MiB held open)
+                                 {1, 16, 6}, {1, 16, 7}, {1, 20, 5}, {1, 20, 6}, {1, 24, 4}, {1, 24, 5}, {1, 28, 4}, {1, 28, 5}, {1, 32, 4},
+                                 {1, 32, 5}, {1, 40, 4}};
     const int(*tab)[3] = out16 ? k16 : k32;
     int ncand = out16 ? (int)(sizeof(k16) / sizeof(k16[0])) : (int)(sizeof(k32) / sizeof(k32[0]));
     cand cands[40];

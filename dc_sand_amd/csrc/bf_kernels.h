@@ -148,11 +148,11 @@ struct bf_bacc_args {
     uint32_t plain_stores; // int8 form: ordinary instead of nontemporal stores
     uint32_t wg_per_cu;    // staged int8 form: at most this many workgroups resident per CU (0 = as many as fit)
     uint32_t unstaged;     // int8 form, <= 64 antennas: operands straight from global memory instead of through LDS
-    uint32_t order;        // workgroup numbering: 1 = round 2's (beam group fastest, channels spread over the XCDs)
+    uint32_t order;        // workgroup numbering: 0 = the launcher's choice, 1 = as dispatched (round 2), 2 = a contiguous eighth per XCD, 3 = sharers always grouped
     uint32_t probe;        // 1 = stores only, 2 = loads and stores without arithmetic, 3 = stores without coefficients either,
                            // 4 = as 3 with one contiguous KiB per store instruction
 #endif
-    uint32_t tiles_per_wg, n_bgroups, n_tgroups, nbt_log2; // filled by the launcher
+    uint32_t tiles_per_wg, n_bgroups, n_tgroups, nbt_log2, xcd_group; // filled by the launcher
     dcs_bf_consts k;
 };
 #ifdef DCS_PROBES

@@ -267,8 +267,9 @@ DCS_HD void dcs_sincos_fast(const float x, float *fSin, float *fCos)
 // relative error 1.9e-6 / 1.5e-5, i.e. < 0.004 / 0.03 of a binary16 ulp), ONE conversion of the
 // pair (v_cvt_pk_f16_f32, round to nearest even), then the quadrant on the packed word:
 // halves rotated by 16 * (n mod 2) with v_alignbit_b32, sign of sin = bit 1 of n, sign of
-// cos = bit 1 of n + 1, two v_bitop3_b32.  23 VALU operations per coefficient with the
-// rotation's 6, against 28-30 for the fp32-then-round form.
+// cos = bit 1 of n + 1, both from one v_lshlrev_b64 of a constant and applied by one v_xor_b32.
+// 21 VALU operations per coefficient with the rotation's 6 (23 in round 2), against 28-30 for
+// the fp32-then-round form.
 // tests/test_numerics.py sweeps EVERY fp32 argument below 32768: each half is within one
 // binary16 ulp of RN16 of the correctly rounded value (it IS that value for 99.8 % of them,
 // 99.1 % in [1, 512)), and the count that differs from RN16(fp32 path) is reported.
@@ -342,12 +343,13 @@ DCS_HD uint32_t dcs_sincos_half2(const float x)
 #else
     const uint32_t sw = (amt & 16u) ? ((p >> 16) | (p << 16)) : p;
 #endif
-    const uint32_t t = dcs_xor_sign_of(sw, q << 30); // sin (high half): sign = bit 1 of n
-#if defined(__HIP_DEVICE_COMPILE__)
-    return __builtin_amdgcn_bitop3_b32((q + 1u) << 14, t, 0x8000u, 0x6c); // cos (low half): sign = bit 1 of n + 1
-#else
-    return t ^ (((q + 1u) << 14) & 0x8000u);
-#endif
+    // Both sign bits from ONE 64-bit shift: the constant 0x00000000'80008000 shifted left by 16 * (n mod 4) -- the low six
+    // bits of the rotate amount, which the hardware's shifter takes as they are --, high word:
+    //   n mod 4 = 0: 0            1: 0x00008000 (cos)   2: 0x80008000 (both)   3: 0x80000000 (sin)
+    // i.e. sin's sign = bit 1 of n, cos's = bit 1 of n + 1.  v_lshlrev_b64 + v_xor_b32 where round 2 had two shifts and two
+    // v_bitop3_b32: 21 instead of 23 vector operations per coefficient, +5 % on the VALU-issue-bound b16 generator
+    // (profiles/r03_fp16.md; the 64-bit shift issues like a 32-bit one).
+    return sw ^ (uint32_t)((0x80008000ull << (amt & 63u)) >> 32);
 }
 
 #endif // DCS_BF_MATH_H

@@ -289,7 +289,7 @@ struct dcs_bf_tuning { /* ABI 3: ten int32_t; the measurement knobs of ABI 2 liv
                               * proven.  Bit 2 (value 4) OPTS IN to the b16 arithmetic form: where the output is b16
                               * and no pair of a wave needs the slow path (|fRotation| < 32000), sin and cos are evaluated to binary16
                               * accuracy (two-term reduction, degree 5 / 4) and converted once, instead of rounding the
-                              * 1-ULP fp32 pair: 23 instead of 28 VALU operations per coefficient.  Every half is within
+                              * 1-ULP fp32 pair: 21 instead of 28 VALU operations per coefficient.  Every half is within
                               * one binary16 ulp of RN16(correctly rounded value) for EVERY fp32 argument below 32768, and
                               * equal to it for 99.8 % of them (0.9 % differ in [1, 32768); tests/test_numerics.py, by
                               * exhaustion).  The reference rounds whatever __sincosf returned and never checks it
@@ -310,7 +310,7 @@ int dcs_bf_set_tuning(dcs_bf_context *ctx, const struct dcs_bf_tuning *t);
  * first launches after a change of access pattern run slower, then times ~3 ms; the four best meet the
  * library's shape-aware default in a play-off, and a challenger replaces the default only when it is
  * more than 0.7 % faster: ~1 s in all); blocks on events, so it cannot be captured in a graph.  The
- * result is CACHED in the context per output width -- a second call returns it at once;
+ * result is CACHED in the context per output width (b16: per arithmetic form too, math_mode bit 2 selects another kernel) -- a second call returns it at once;
  * dcs_bf_set_tuning(ctx, NULL) forgets it -- and *chosen (may be NULL) reports it.  Knobs set
  * explicitly with dcs_bf_set_tuning keep precedence over it.  Results do not depend on the geometry
  * (every one gives the same bits). */

@@ -36,7 +36,8 @@ struct dcs_probe_knobs {
     int32_t bacc_plain;     /* ordinary instead of nontemporal stores */
     int32_t bacc_wg_per_cu; /* staged form: at most this many workgroups resident per CU */
     int32_t bacc_unstaged;  /* <= 64 antennas: operands straight from global memory instead of through LDS */
-    int32_t bacc_order;     /* workgroup numbering: 0 = the product's (XCD-aware), 1 = round 2's (beam group fastest) */
+    int32_t bacc_order;     /* workgroup numbering: 0 = the product's choice, 1 = as dispatched (round 2), 2 = one contiguous
+                             * eighth of the order per XCD, 3 = the workgroups sharing a channel's samples always on one XCD */
 };
 int dcs_probe_set_knobs(dcs_bf_context *ctx, const struct dcs_probe_knobs *k);
 

@@ -1594,7 +1594,8 @@ def test_autotune_measures_a_large_shape_once(gpu, oracle):
 @pytest.mark.parametrize("A,B,C,nt", [(64, 16, 64, 256), (64, 16, 5, 32), (64, 64, 7, 64), (64, 40, 3, 48), (8, 4, 5, 16), (37, 21, 9, 48),
                                        (130, 3, 4, 16), (4, 40, 7, 32), (9, 5, 3, 16), (129, 33, 2, 32), (256, 17, 2, 16), (1, 1, 1, 16),
                                        (66, 70, 2, 80), (128, 16, 3, 64), (192, 48, 2, 32), (200, 20, 2, 32), (64, 1024, 1, 32),
-                                       (64, 32, 3, 112), (64, 24, 2, 272), (64, 16, 2, 592), (48, 16, 3, 48), (64, 64, 2, 272)])
+                                       (64, 32, 3, 112), (64, 24, 2, 272), (64, 16, 2, 592), (48, 16, 3, 48), (64, 64, 2, 272),
+                                       (256, 64, 2, 272), (100, 20, 3, 112), (256, 16, 1, 1600), (65, 16, 2, 48)])
 def test_beamform_accumulated_on_the_matrix_cores(gpu, oracle, A, B, C, nt, math_mode):
     """dcs_bf_beamform_accumulated: the coefficients of ONE time applied to nt samples as two real contractions over the
     antennas on the matrix cores, against the verifier's beamformer with the coefficient held
@@ -1607,7 +1608,10 @@ def test_beamform_accumulated_on_the_matrix_cores(gpu, oracle, A, B, C, nt, math
     sum in exact (fp64) arithmetic of the oracle's fp32 coefficients: 2.5e-7 * sum_a |sample_a| + 2e-7 * |sum|.
     Shapes cover every beam-tile count (1, 2, 4 per workgroup: coefficients shared by 4, 2, 1 waves), ragged antennas /
     beams / sample blocks, odd block counts and more than 16 blocks per (channel, beam group) (several workgroups), 1-4
-    64-antenna chunks (whole and partial) and the 256-antenna limit."""
+    64-antenna chunks (whole and partial) and the 256-antenna limit -- above 64 antennas the kChain form (round 3: the
+    coefficients in LDS, the integer sums chained through the chunks by the matrix instruction's accumulator), with fewer
+    sample blocks than waves (waves that only make their chunk's coefficients), odd pair counts and several workgroups
+    per channel."""
     from dc_sand_amd import BeamformerParameters
     from dc_sand_amd.generator import SteeringCoefficientGenerator, delta_times, simulate_input
 

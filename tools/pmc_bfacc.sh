@@ -8,6 +8,7 @@ set -e
 SHAPE=${1:-64x256x1024x256}
 R=${GRAFT_REPO_ROOT:-$PWD}
 OUT=${2:-$R/gpurun_out/pmc_bfacc_$SHAPE}
+case $OUT in /*) ;; *) OUT=$R/$OUT ;; esac
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 for pass in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU" \
