@@ -599,12 +599,13 @@ bf_geom shape_default_geometry(const dcs_bf_context *c, bool out16, uint32_t nc,
     if (want_terms_table(c, out16, g, nc, nt)) {
         g.tpb = 1;
         if (out16) {
-            // b16 arithmetic form (VALU-issue- and power-bound at 21 operations per coefficient): what decides is the number
-            // of channel rows the resident workgroups hold open, chan_per_block x workgroups per CU -- 96-120 rows (24-30 MiB
-            // of output) is the ridge on every box swept, 140-190 falls off a cliff whose position moves between boxes
-            // (profiles/r03_fp16.md): 24 channels x 5 workgroups per CU
-            g.cpb = half ? 24u : 64u;
-            g.wpc = half ? 5 : 0;
+            // fp16 is VALU-issue- and power-bound (27 / 21 vector operations per coefficient); beside that, what decides is the
+            // number of channel rows the resident workgroups hold open, chan_per_block x workgroups per CU.  b16 arithmetic
+            // form: a ridge at 100-150 rows (25-38 MiB of output) on every box swept, and a cliff (-12 %) beyond whose position
+            // moves between boxes (140-190 rows): 20 channels x 6 workgroups per CU.  fp32-grade form: ridge at 200-320 rows,
+            // cliff at 64 x 6: 48 channels x 5 (profiles/r03_fp16.md)
+            g.cpb = half ? 20u : 48u;
+            g.wpc = half ? 6 : 5;
         } else {
             g.cpb = 8u;
             g.wpc = 6;

@@ -237,6 +237,26 @@ __global__ void __launch_bounds__(kBlock) bf_tiled_kernel(const std::conditional
         }
     } else if (!HALF && !wave_slow) {
         dispatch_fast(a.k.uDiv3Exact != 0u, wave_low, [&](auto div3, auto lowdeg) {
+            if constexpr (OUT16) {
+                // b16 output from the fp32-grade arithmetic (the default): the pair is converted once and the quadrant
+                // logic runs on the packed word (dcs_sincos_fast_half2: bit for bit RN-even of the fp32 pair)
+                for (uint32_t c = cbeg + row; c < cend; c += ROWS) {
+                    const float fChan = (float)(a.c0 + c);
+                    uint32_t w[PPL];
+#pragma unroll
+                    for (int j = 0; j < PPL; j++)
+                        w[j] = dcs_sincos_fast_half2<decltype(lowdeg)::value>(dcs_rotation<decltype(div3)::value>(fRate[j], fPhase0[j], fChan, D, y));
+                    if constexpr (ALIGNED) {
+                        store_global<NT>(reinterpret_cast<uintx4 *>(dst), uintx4{w[0], w[1], w[2], w[3]});
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < PPL; j++)
+                            if (p0 + j < a.n_pairs) store_global<NT>(reinterpret_cast<uint32_t *>(dst) + j, w[j]);
+                    }
+                    dst += step;
+                }
+                return;
+            }
 #pragma unroll 2
             for (uint32_t c = cbeg + row; c < cend; c += ROWS) {
                 const float fChan = (float)(a.c0 + c);

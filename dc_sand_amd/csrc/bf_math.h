@@ -217,8 +217,10 @@ DCS_HD uint32_t dcs_xor_sign_of(const uint32_t v, const uint32_t m)
 #endif
 }
 
+// sin r, cos r of the reduced argument and the word whose low bits are the quadrant number n (mod 2^22): the part of the
+// fp32-grade sincos that both finishers below share.
 template <bool LOWDEG = false>
-DCS_HD void dcs_sincos_fast(const float x, float *fSin, float *fCos)
+DCS_HD void dcs_sincos_core(const float x, float *fSinR, float *fCosR, uint32_t *uQ)
 {
     const float nb = dcs_fmaf(x, DCS_TWO_OVER_PI, DCS_RINT_MAGIC);
     const float n = nb - DCS_RINT_MAGIC;
@@ -243,9 +245,17 @@ DCS_HD void dcs_sincos_fast(const float x, float *fSin, float *fCos)
         pc = dcs_fmaf(pc, s, DCS_C1);
     }
     pc = dcs_fmaf(pc, s, -0.5f);
-    const float sr = dcs_fmaf(s * r, ps, r);
-    const float cr = dcs_fmaf(s, pc, 1.0f);
+    *fSinR = dcs_fmaf(s * r, ps, r);
+    *fCosR = dcs_fmaf(s, pc, 1.0f);
+    *uQ = q;
+}
 
+template <bool LOWDEG = false>
+DCS_HD void dcs_sincos_fast(const float x, float *fSin, float *fCos)
+{
+    float sr, cr;
+    uint32_t q;
+    dcs_sincos_core<LOWDEG>(x, &sr, &cr, &q);
     // q mod 4:  0: (cr, sr)  1: (-sr, cr)  2: (-cr, -sr)  3: (sr, -cr)
     // sin's sign = bit 1 of q; cos's sign = bit 1 xor bit 0.
     const uint32_t t30 = q << 30, t31 = q << 31;           // bit 1 / bit 0 moved to the sign position
@@ -254,6 +264,25 @@ DCS_HD void dcs_sincos_fast(const float x, float *fSin, float *fCos)
     const uint32_t uc = dcs_f32_bits(swap ? -sr : cr);     // one v_cndmask with a neg modifier (sign flip == xor t31)
     *fSin = dcs_bits_f32(dcs_xor_sign_of(us, t30));
     *fCos = dcs_bits_f32(dcs_xor_sign_of(uc, t30));
+}
+
+// The quadrant on a PACKED pair p = {low half = cos r, high half = sin r}, n = q mod 4:
+//   0: (cr, sr)   1: (-sr, cr)   2: (-cr, -sr)   3: (sr, -cr)      as (cos x, sin x)
+// halves rotated by 16 * (n mod 2) with v_alignbit_b32; both sign bits from ONE 64-bit shift: the constant
+// 0x00000000'80008000 shifted left by 16 * (n mod 4) -- the low six bits of the rotate amount, which the hardware's shifter
+// takes as they are --, high word:   n = 0: 0    1: 0x00008000 (cos)    2: 0x80008000 (both)    3: 0x80000000 (sin)
+// i.e. sin's sign = bit 1 of n, cos's = bit 1 of n + 1.  v_lshlrev_b32, v_alignbit_b32, v_lshlrev_b64, v_xor_b32: four
+// operations where round 2 had six (two shifts and two v_bitop3_b32 for the signs): +5 % on the VALU-issue-bound b16
+// generator (profiles/r03_fp16.md; the 64-bit shift issues like a 32-bit one).
+DCS_HD uint32_t dcs_quadrant_half2(const uint32_t p, const uint32_t q)
+{
+    const uint32_t amt = q << 4; // bit 4 = n mod 2: rotate the halves by 16 when n is odd; bits 4-5 = n mod 4
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t sw = __builtin_amdgcn_alignbit(p, p, amt);
+#else
+    const uint32_t sw = (amt & 16u) ? ((p >> 16) | (p << 16)) : p;
+#endif
+    return sw ^ (uint32_t)((0x80008000ull << (amt & 63u)) >> 32);
 }
 
 // ---------------------------------------------------------------------------
@@ -335,21 +364,25 @@ DCS_HD uint32_t dcs_sincos_half2(const float x)
     // 28-instruction fp32-then-round form (profiles/r02_fp16.md).
     asm("" : "+v"(sr), "+v"(cr));
 #endif
-    const uint32_t p = dcs_pack_half2(cr, sr);
-    // n mod 4:  0: (cr, sr)  1: (-sr, cr)  2: (-cr, -sr)  3: (sr, -cr)   as (cos, sin)
-    const uint32_t amt = q << 4; // bit 4 = n mod 2: rotate the halves by 16 when n is odd
+    return dcs_quadrant_half2(dcs_pack_half2(cr, sr), q);
+}
+
+// The fp32-GRADE pair (dcs_sincos_fast: <= 1 ULP in fp32, three-term reduction, full or low-degree polynomials) delivered
+// as the packed b16 word: converted ONCE, before the quadrant logic, which then works on the packed word (4 operations)
+// instead of on two fp32 values (7 + the conversion).  Bit for bit RN-even(dcs_sincos_fast's fp32 pair): swapping halves
+// and flipping signs commute with rounding to nearest even.  tests/test_numerics.py checks that identity for EVERY fp32
+// argument of the fast range; the default b16 output (math_mode 0) is this function since round 3 (27 instead of 30
+// vector operations per coefficient with the rotation's).
+template <bool LOWDEG = false>
+DCS_HD uint32_t dcs_sincos_fast_half2(const float x)
+{
+    float sr, cr;
+    uint32_t q;
+    dcs_sincos_core<LOWDEG>(x, &sr, &cr, &q);
 #if defined(__HIP_DEVICE_COMPILE__)
-    const uint32_t sw = __builtin_amdgcn_alignbit(p, p, amt);
-#else
-    const uint32_t sw = (amt & 16u) ? ((p >> 16) | (p << 16)) : p;
+    asm("" : "+v"(sr), "+v"(cr)); // the conversion stays ONE v_cvt_pk_f16_f32 of the ROUNDED fp32 pair (no v_fma_mix*_f16: see dcs_sincos_half2)
 #endif
-    // Both sign bits from ONE 64-bit shift: the constant 0x00000000'80008000 shifted left by 16 * (n mod 4) -- the low six
-    // bits of the rotate amount, which the hardware's shifter takes as they are --, high word:
-    //   n mod 4 = 0: 0            1: 0x00008000 (cos)   2: 0x80008000 (both)   3: 0x80000000 (sin)
-    // i.e. sin's sign = bit 1 of n, cos's = bit 1 of n + 1.  v_lshlrev_b64 + v_xor_b32 where round 2 had two shifts and two
-    // v_bitop3_b32: 21 instead of 23 vector operations per coefficient, +5 % on the VALU-issue-bound b16 generator
-    // (profiles/r03_fp16.md; the 64-bit shift issues like a 32-bit one).
-    return sw ^ (uint32_t)((0x80008000ull << (amt & 63u)) >> 32);
+    return dcs_quadrant_half2(dcs_pack_half2(cr, sr), q);
 }
 
 #endif // DCS_BF_MATH_H

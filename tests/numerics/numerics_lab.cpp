@@ -106,6 +106,27 @@ static void *half_worker(void *arg)
     return NULL;
 }
 
+/* dcs_sincos_fast_half2 (the packed b16 word from the fp32-grade pair, quadrant logic on the packed word) against
+ * RN-even of dcs_sincos_fast's fp32 pair, bit for bit: over_a counts the arguments where they differ. */
+template <bool LOW>
+static void *fast_half2_worker(void *arg)
+{
+    struct sweep_job *j = (struct sweep_job *)arg;
+    for (uint32_t u = j->lo; u < j->hi; u++) {
+        for (int neg = 0; neg < 2; neg++) {
+            const float x = dcs_bits_f32(u | (neg ? 0x80000000u : 0u));
+            float fs, fc;
+            dcs_sincos_fast<LOW>(x, &fs, &fc);
+            const uint32_t want = dcs_f32_to_f16_bits(fc) | (dcs_f32_to_f16_bits(fs) << 16);
+            if (dcs_sincos_fast_half2<LOW>(x) != want) {
+                if (j->over_a == 0) j->worst_a = u | (neg ? 0x80000000u : 0u);
+                j->over_a++;
+            }
+        }
+    }
+    return NULL;
+}
+
 static void *div_worker(void *arg)
 {
     struct sweep_job *j = (struct sweep_job *)arg;
@@ -206,6 +227,18 @@ void lab_half_sweep(uint32_t lo_bits, uint32_t hi_bits, int nthreads, uint64_t *
     res[0] = o.max_a; res[1] = o.max_b; res[2] = o.over_a; res[3] = o.over_b;
     res[4] = o.unfaithful_a; res[5] = o.unfaithful_b; res[6] = o.over_f_a; res[7] = o.over_f_b;
     res[8] = o.worst_a; res[9] = o.worst_b;
+}
+
+/* res = {n_arguments_where dcs_sincos_fast_half2 != RN16(dcs_sincos_fast), first_such_x_bits}; both signs of every
+ * fp32 with bit pattern in [lo_bits, hi_bits). */
+void lab_fast_half2_sweep(int lowdeg, uint32_t lo_bits, uint32_t hi_bits, int nthreads, uint64_t *res)
+{
+    struct sweep_job p = {}, o;
+    p.lo = lo_bits;
+    p.hi = hi_bits;
+    run_sweep(lowdeg ? fast_half2_worker<true> : fast_half2_worker<false>, &p, nthreads, &o);
+    res[0] = o.over_a;
+    res[1] = o.worst_a;
 }
 
 void lab_sincos_half2(const float *x, size_t n, uint32_t *packed)

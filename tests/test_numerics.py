@@ -31,6 +31,7 @@ def lab():
     L.lab_sincos.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p]
     L.lab_half_sweep.argtypes = [ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int, ctypes.POINTER(ctypes.c_uint64)]
     L.lab_sincos_half2.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+    L.lab_fast_half2_sweep.argtypes = [ctypes.c_int, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int, ctypes.POINTER(ctypes.c_uint64)]
     L.lab_generate_fast.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int32, ctypes.c_float, ctypes.c_float,
                                     ctypes.c_size_t, ctypes.c_size_t, ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]
     return L
@@ -99,6 +100,18 @@ def test_b16_arithmetic_form_every_fp32_of_the_fast_range(lab):
     lab.lab_half_sweep(_bits(2.0 ** -40), _bits(512.0), 8, res)
     n = _bits(512.0) - _bits(2.0 ** -40)
     assert res[4] < 3e-3 * n and res[5] < 3e-3 * n
+
+
+def test_default_b16_word_is_rne_of_the_fp32_pair_for_every_fp32(lab):
+    """The DEFAULT b16 output (math_mode 0) converts the fp32-grade (sin r, cos r) pair once and does the quadrant logic on the
+    packed word (dcs_sincos_fast_half2; round 3: 4 operations instead of 7 on two fp32 values).  Swapping halves and flipping
+    signs commute with rounding to nearest even, so the word must equal RN-even of dcs_sincos_fast's fp32 pair BIT FOR BIT --
+    checked for every fp32 argument of either sign in [2^-40, 32768) with the full polynomials and in [2^-40, 512) with
+    the low-degree set (the ranges they are used on), zeros and the smallest arguments included."""
+    res = (ctypes.c_uint64 * 2)()
+    for lowdeg, lo, hi in ((0, _bits(2.0 ** -40), _bits(32768.0)), (1, _bits(2.0 ** -40), _bits(512.0)), (0, 0, 64), (1, 0, 64)):
+        lab.lab_fast_half2_sweep(lowdeg, lo, hi, 8, res)
+        assert res[0] == 0, (lowdeg, hex(lo), hex(hi), res[0], hex(res[1]))
 
 
 def test_sincos_symmetry_and_tiny_arguments(lab, oracle):

@@ -224,7 +224,17 @@ def cmd_bfacc(args):
         g.upload_delays(simulate_input(bp))
         ab, bb = A * C * nt * 2, B * C * nt * 8
         d_ant, d_beams = device.mem_alloc(ab), device.mem_alloc(bb)
-        device.memset(d_ant, 3, ab)
+        if args.random:  # noise-like samples (what a telescope delivers): a 32 MiB seeded block repeated
+            blk = min(ab, 32 << 20)
+            device.memcpy_htod(d_ant, np.random.default_rng(0xA17).integers(-128, 128, size=blk, dtype=np.int8))
+            off = blk
+            while off < ab:
+                n = min(off, ab - off)
+                device.memcpy_dtod(int(d_ant) + off, d_ant, n)
+                off += n
+            device.synchronize()
+        else:
+            device.memset(d_ant, 3, ab)
         for mode in (int(m) for m in args.modes.split(",")):
             g.set_tuning(math_mode=mode)
             ms = min(per_launch_ms(lambda: g.beamform_accumulated(d_ant, ab, d_beams, bb, nt, t_coeff=1)) for _ in range(2))
@@ -442,6 +452,7 @@ def main():
     p = sub.add_parser("bfacc")
     p.add_argument("--shape", default="", help="AxBxCxNT: one shape only (PMC passes)")
     p.add_argument("--modes", default="0,8", help="math_mode values: 0 = int8 fixed point, 8 = fp32 chain")
+    p.add_argument("--random", action="store_true", help="noise-like int8 samples instead of a constant byte (the matrix pipe's power depends on the data)")
     p = sub.add_parser("stream")
     p.add_argument("--model-step-us", type=float, default=200.0)
     sub.add_parser("pmc")
