@@ -235,10 +235,20 @@ def extras(gen, bp, out, out_bytes, sh, device, sustain_seconds: float, samples:
     from dc_sand_amd import BeamformerParameters
     from dc_sand_amd.generator import SteeringCoefficientGenerator, simulate_input
 
-    def timed(fn, n=20, warm=5):
-        for _ in range(warm):
-            fn()
+    def timed(fn, n=20, warm=5, settle_ms=30.0, timed_ms=12.0):
+        """ms per call at steady state: at least `warm` calls AND ~settle_ms on this access pattern first (the first launches
+        after a change of pattern run 3-10 % slow: DESIGN.md 5.1), then ONE event pair around max(n, ~timed_ms worth of) calls."""
         e0, e1 = device.Event(), device.Event()
+        fn()
+        e0.record(sh)
+        fn()
+        fn()
+        e1.record(sh)
+        e1.synchronize()
+        one = max(e1.elapsed_ms_since(e0) / 2, 1e-3)
+        for _ in range(int(min(4000, max(warm, settle_ms / one)))):
+            fn()
+        n = int(min(4000, max(n, timed_ms / one)))
         e0.record(sh)
         for _ in range(n):
             fn()
