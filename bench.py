@@ -339,6 +339,9 @@ def extras(gen, bp, out, out_bytes, sh, device, sustain_seconds: float, samples:
     full_us, full_bytes = tick_period_us(bp.NR_CHANNELS, ticks=60, warm=6)
     full_host_us, _ = tick_period_us(bp.NR_CHANNELS, ticks=60, warm=6, table="host")
     full_dev_us, _ = tick_period_us(bp.NR_CHANNELS, ticks=60, warm=6, table="device")
+    # slabs below 2 GiB run the generator's other variant (terms per workgroup): let the library measure ITS geometry too
+    # (cached per variant; the full tensor's stays), as the headline does for the 16 GiB launch
+    slab_tuning = gen.autotune(out.data_ptr(), min(out_bytes, 2560 * bp.n_pairs * 8), stream=sh)
     best = None
     for nc in (1536, 2048, 2304, 2432, 2560, 2688, 2816):
         if nc > bp.NR_CHANNELS:
@@ -355,6 +358,7 @@ def extras(gen, bp, out, out_bytes, sh, device, sustain_seconds: float, samples:
     res["streaming_cfg5"] = {"cadence_target_us": 200.0, "model_time_step_us": 200.0, "launch": "hipGraph replay, dcs_bf_stream_tick_dt",
                              "full_tensor_period_us": full_us, "full_tensor_TBps": full_bytes / full_us / 1e6,
                              "meets_200us_full_tensor": bool(full_us <= 200.0), "largest_slab_at_200us": best,
+                             "slab_launch_geometry": {k: slab_tuning[k] for k in ("tiles_per_block", "chan_per_block", "wg_per_cu")},
                              "new_table_every_tick": {"full_tensor_host_table_period_us": full_host_us,
                                                       "full_tensor_device_table_period_us": full_dev_us, "slab_at_200us": every,
                                                       "note": "host: memcpy into a ring of 4 pinned buffers + H2D copy in front of the "

@@ -125,13 +125,15 @@ struct dcs_bf_context {
     float *d_tt_terms;      // [kTermsInline][pairs_pad][2]
     uint32_t *d_tt_flags;   // [kTermsInline][pairs_pad/64]
     dcs_bf_tuning tune;     // the caller's explicit knobs (dcs_bf_set_tuning); 0 / -1 = not set
-    // what dcs_bf_autotune measured for this context's shape, per kernel family: [0] = fp32, [1] = fp16 from the
-    // fp32-grade arithmetic, [2] = fp16 from the b16 arithmetic form (math_mode bit 2: another kernel, another optimum);
-    // used for large launches wherever the caller has not set a knob explicitly
+    // what dcs_bf_autotune measured for this context's shape, per KERNEL: [0] = fp32, [1] = fp16 from the fp32-grade
+    // arithmetic, [2] = fp16 from the b16 arithmetic form (math_mode bit 2), each x {terms computed by every workgroup,
+    // terms from the pre-pass table} -- different kernels with different optima (round 2 kept one result per output width and
+    // ran a 1.2 GB streaming slab, which takes the first variant, at the geometry tuned for the 16 GiB launch, which takes
+    // the second: 6.2 instead of 6.9 TB/s); used for large launches wherever the caller has not set a knob explicitly
     struct tuned_geom {
         bool valid;
         int32_t tpb, cpb, wpc; // wpc: -1 = unlimited
-    } tuned[3];
+    } tuned[3][2];
 #ifdef DCS_PROBES
     dcs_probe_knobs probe;  // measurement knobs (include/dcs_probes.h); the product build has no such member
 #endif
@@ -497,7 +499,7 @@ int dcs_bf_set_tuning(dcs_bf_context *c, const dcs_bf_tuning *t)
         c->k.uDiv3Exact = c->div3_verified;
         c->k.fLowDegLimit = 500.0f;
         c->k.uHalfMath = 0u;
-        c->tuned[0].valid = c->tuned[1].valid = c->tuned[2].valid = false; // forget what dcs_bf_autotune measured, too
+        std::memset(c->tuned, 0, sizeof(c->tuned)); // forget what dcs_bf_autotune measured, too
         return DCS_OK;
     }
     if (t->form < 0 || t->form > 3) return DCS_ERR_INVALID_ARGUMENT;
@@ -636,7 +638,7 @@ bf_geom pick_geometry(const dcs_bf_context *c, bool out16, uint32_t nc, uint32_t
 {
     constexpr uint64_t kResident = 256u * 8u;
     bf_geom g = shape_default_geometry(c, out16, nc, nt);
-    const dcs_bf_context::tuned_geom &t = c->tuned[tuned_slot(c, out16)];
+    const dcs_bf_context::tuned_geom &t = c->tuned[tuned_slot(c, out16)][want_terms_table(c, out16, g, nc, nt) ? 1 : 0];
     if (t.valid && tiled_blocks(c->n_pairs, out16, t.tpb, (uint32_t)t.cpb, nc, nt) > kResident) {
         g.tpb = t.tpb;
         g.cpb = (uint32_t)t.cpb;
@@ -1246,7 +1248,9 @@ int dcs_bf_autotune(dcs_bf_context *c, int bitwidth, void *d_out, size_t out_byt
         const int cap = refuse_if_capturing(s); // the tuner blocks on events
         if (cap != DCS_OK) return cap;
     }
-    dcs_bf_context::tuned_geom &slot = c->tuned[tuned_slot(c, out16)];
+    // (which of the two variants launches of this size take: decided from the shape's default geometry, as pick_geometry does)
+    dcs_bf_context::tuned_geom &slot =
+        c->tuned[tuned_slot(c, out16)][want_terms_table(c, out16, shape_default_geometry(c, out16, nc, nt_tune), nc, nt_tune) ? 1 : 0];
 
     auto report = [&]() {
         if (!chosen) return;

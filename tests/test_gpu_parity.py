@@ -1582,7 +1582,18 @@ def test_autotune_measures_a_large_shape_once(gpu, oracle):
     for ch in (0, 4097, 16383):
         gpu.memcpy_dtoh(host, int(buf) + ch * row)
         assert oracle.max_ulp(host, oracle.generate(op, table, 9, 1, ch, 1), 1)[1] == 0
-    g.set_tuning()  # forgets the cached choice
+    # a 1 GiB slab of the same shape takes the OTHER kernel variant (terms computed per workgroup, not read from the pre-pass
+    # table): its geometry is measured and cached separately, and the full tensor's stays cached beside it
+    t0 = time.perf_counter()
+    slab_choice = g.autotune(buf, nbytes // 2)
+    assert time.perf_counter() - t0 > 0.2
+    t0 = time.perf_counter()
+    assert g.autotune(buf, nbytes) == chosen and g.autotune(buf, nbytes // 2) == slab_choice
+    assert time.perf_counter() - t0 < 0.02
+    g.generate_slab(buf, nbytes // 2, 100, bp.NR_CHANNELS // 2, t0=9, nt=1)
+    gpu.memcpy_dtoh(host, int(buf) + 17 * row)
+    assert oracle.max_ulp(host, oracle.generate(op, table, 9, 1, 117, 1), 1)[1] == 0
+    g.set_tuning()  # forgets the cached choices
     t0 = time.perf_counter()
     g.autotune(buf, nbytes)
     assert time.perf_counter() - t0 > 0.2
