@@ -241,8 +241,9 @@ __global__ void __launch_bounds__(kBlock) bf_beamform_acc_kernel(const bf_bacc_a
 // A wave owns one 16-beam tile of one channel and some of the workgroup's 16-sample blocks.  Its coefficients
 // (64 antennas = 6 operands of 4 registers: 3 digits x {re, im}) are made once, in registers (waves that own the
 // same tile make a share each and exchange them through LDS).  Up to 64 antennas the workgroup's sample blocks
-// (at most 16 = 32 KiB) travel to LDS by LDS-DMA while the coefficients are being made; beyond, the antennas are
-// split over the workgroup's waves (64 each), which load their own operands and add their partial sums up in LDS.  Per pair of blocks and 64 antennas: 16 four-byte operand reads per
+// (at most 16 = 32 KiB) travel to LDS by LDS-DMA while the coefficients are being made; beyond (kChain, round 3), the
+// workgroup's waves make the coefficients of 64 antennas each, put them in LDS, and every wave walks all the antenna
+// chunks of its own sample blocks with the matrix instruction's accumulator.  Per pair of blocks and 64 antennas: 16 four-byte operand reads per
 // lane, a 4 x 4 byte transpose into four K = 64 operands (slot (lane >> 4, byte p) of BOTH operands is antenna
 // 64 ch + 4 p + (lane >> 4): the contraction index may be permuted freely as long as both sides agree), 12 MFMAs,
 // ~130 vector instructions to recombine, 4 sixteen-byte stores.  The arithmetic is hidden entirely: with its stores
@@ -283,15 +284,13 @@ __device__ __forceinline__ uint32_t fixed_word(float w)
 //       recombination arithmetic, and a result that is one fp32 rounding closer to the exact sum.
 // FULL: nr_stations is a multiple of 64 (no antenna masks, immediate load offsets).
 enum { kStaged = 0, kDirect = 1, kSplit = 2, kChain = 3 };
-#ifndef DCS_CHAIN_DEPTH
-#define DCS_CHAIN_DEPTH 2 // sample buffers of the kChain walk: the samples of step s + DEPTH - 1 are requested while step s is worked on
-#endif
-#ifndef DCS_CHAIN_WAVES
-#define DCS_CHAIN_WAVES 3 // waves per SIMD the kChain form is allocated for (147 VGPRs; 4 would need <= 128: measured, profiles/r03_fused.md)
-#endif
+// kChain is allocated for 3 waves per SIMD (147 VGPRs) and walks with TWO sample buffers.  Tried and not kept (profiles/r03_fused.md):
+// 4 waves per SIMD (<= 128 registers: 4 spills to scratch), a third sample buffer (168 registers, 2 spills), and the next step's
+// loads issued before this step's wait (1-4 % slower).
+constexpr int kChainWaves = 3;
 
 template <int FORM, bool FULL>
-__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(FORM == kSplit ? (FULL ? 3 : 2) : (FORM == kChain ? DCS_CHAIN_WAVES : (FULL || FORM == kStaged ? 4 : 3)))))
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(FORM == kSplit ? (FULL ? 3 : 2) : (FORM == kChain ? kChainWaves : (FULL || FORM == kStaged ? 4 : 3)))))
 bf_beamform_i8_kernel(const bf_bacc_args a)
 {
     constexpr bool STAGED = FORM == kStaged, SPLIT = FORM == kSplit, CHAIN = FORM == kChain;
@@ -450,7 +449,7 @@ bf_beamform_i8_kernel(const bf_bacc_args a)
     const bool second = lm >= 8u;                    // this lane's columns belong to block B of the pair
     const uint32_t last = n_blocks - 1u;
     const uint32_t voff = lg * 32u + m * 4u;
-    uint32_t cur[CHAIN ? DCS_CHAIN_DEPTH : 2][16];
+    uint32_t cur[2][16];
     // "every loaded register is needed HERE": keeps the compiler from sinking a load set into the trip that consumes it
     auto arrived = [&](uint32_t (&v)[16]) {
         asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]));
@@ -685,23 +684,16 @@ bf_beamform_i8_kernel(const bf_bacc_args a)
         if (lane == 0u) nanw[2u * wave] = has_chunk ? nan_re : 0u, nanw[2u * wave + 1u] = has_chunk ? nan_im : 0u;
         __syncthreads(); // the kernel's only barrier
         if (idle) return;
-#if DCS_CHAIN_DEPTH == 3
-        {
-            const uint32_t nch = (a.A + 63u) / 64u; // step 1 of this wave: (pair 0, chunk 1), or (pair 1, chunk 0) of a one-chunk problem
-            if (nch * ((n_blocks + 1u) >> 1) > 1u) fetch(cur[1], nch > 1u ? 0u : 2u, nch > 1u ? 1u : 0u);
-        }
-#endif
         nan_re = nanw[0] | nanw[2] | nanw[4] | nanw[6]; // a non-finite coefficient in ANY chunk poisons the row
         nan_im = nanw[1] | nanw[3] | nanw[5] | nanw[7];
         const uint32_t n_chunks = (a.A + 63u) / 64u;
         auto run_chain = [&](auto whole) {
-            // a step = (pair of this wave's blocks, antenna chunk), pair-major; DCS_CHAIN_DEPTH sample buffers in rotation: the
-            // samples of step s + DEPTH - 1 are requested before step s is worked on (steps 0 .. DEPTH - 2 were requested
-            // around the coefficient making)
+            // a step = (pair of this wave's blocks, antenna chunk), pair-major; two sample buffers in turn: the samples of step
+            // s + 1 are requested before step s is worked on (step 0 was requested before the coefficient making)
             const uint32_t n_steps = ((n_blocks + 1u) >> 1) * n_chunks;
             intx4 acc[4][3];
             uint32_t s = 0, chunk = 0, blk = 0;
-            uint32_t f_s = DCS_CHAIN_DEPTH - 1u, f_chunk = (DCS_CHAIN_DEPTH - 1u) % n_chunks, f_blk = 2u * ((DCS_CHAIN_DEPTH - 1u) / n_chunks); // next step to request
+            uint32_t f_s = 1u, f_chunk = 1u % n_chunks, f_blk = 2u * (1u / n_chunks); // next step to request
             auto step = [&](uint32_t (&now)[16], uint32_t (&ahead)[16]) {
                 arrived(now);
                 if (f_s < n_steps) fetch(ahead, f_blk, f_chunk);
@@ -739,14 +731,8 @@ bf_beamform_i8_kernel(const bf_bacc_args a)
                 s++;
             };
             while (s < n_steps) {
-#if DCS_CHAIN_DEPTH == 3
-                step(cur[0], cur[2]);
-                if (s < n_steps) step(cur[1], cur[0]);
-                if (s < n_steps) step(cur[2], cur[1]);
-#else
                 step(cur[0], cur[1]);
                 if (s < n_steps) step(cur[1], cur[0]);
-#endif
             }
         };
         if (bw + 16u <= a.B)

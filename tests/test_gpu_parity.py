@@ -1606,7 +1606,9 @@ def test_autotune_measures_a_large_shape_once(gpu, oracle):
                                        (130, 3, 4, 16), (4, 40, 7, 32), (9, 5, 3, 16), (129, 33, 2, 32), (256, 17, 2, 16), (1, 1, 1, 16),
                                        (66, 70, 2, 80), (128, 16, 3, 64), (192, 48, 2, 32), (200, 20, 2, 32), (64, 1024, 1, 32),
                                        (64, 32, 3, 112), (64, 24, 2, 272), (64, 16, 2, 592), (48, 16, 3, 48), (64, 64, 2, 272),
-                                       (256, 64, 2, 272), (100, 20, 3, 112), (256, 16, 1, 1600), (65, 16, 2, 48)])
+                                       (256, 64, 2, 272), (100, 20, 3, 112), (256, 16, 1, 1600), (65, 16, 2, 48),
+                                       # enough workgroups for the XCD-grouped numbering to leave its identity tail (> 8 x the sharers):
+                                       (64, 1024, 9, 32), (130, 20, 9, 32), (256, 64, 9, 16), (192, 48, 11, 48)])
 def test_beamform_accumulated_on_the_matrix_cores(gpu, oracle, A, B, C, nt, math_mode):
     """dcs_bf_beamform_accumulated: the coefficients of ONE time applied to nt samples as two real contractions over the
     antennas on the matrix cores, against the verifier's beamformer with the coefficient held
