@@ -61,13 +61,9 @@ namespace {
 // 4 x what it writes: -18 % time), and for the staged form from 16 sharers on (+3.5 %; at 2 - 8 sharers the grouped
 // order measured 1.5 - 7 % SLOWER -- four workgroups missing on the same lines of one L2 at the same moment -- so those
 // stay as dispatched).
-__device__ __forceinline__ uint32_t xcd_grouped(uint32_t w, uint32_t total, uint32_t G)
-{
-    const uint32_t full = total - total % (8u * G);
-    if (G <= 1u || w >= full) return w;
-    const uint32_t x = w & 7u, q = w >> 3;
-    return ((q / G) * 8u + x) * G + q % G;
-}
+// (the function itself: bf_kernels.h, bf_xcd_grouped -- host-callable too, so that tests/test_host_abi.py can check the
+// bijection on the CPU through probes/libdcs_probes.so)
+__device__ __forceinline__ uint32_t xcd_grouped(uint32_t w, uint32_t total, uint32_t G) { return bf_xcd_grouped(w, total, G); }
 #ifdef DCS_PROBES
 // A/B of the numbering (dcs_probe_knobs.bacc_order): 0 = the launcher's choice, 1 = as dispatched (round 2), 2 = one
 // contiguous eighth of the order per XCD, 3 = sharers grouped whatever their number

@@ -155,6 +155,19 @@ struct bf_bacc_args {
     uint32_t tiles_per_wg, n_bgroups, n_tgroups, nbt_log2, xcd_group; // filled by the launcher
     dcs_bf_consts k;
 };
+// Dispatch number -> logical workgroup number that puts G consecutive logical workgroups on ONE XCD (the hardware deals
+// workgroup w to XCD w % 8) while the eight XCDs work on eight neighbouring groups: XCD x = w % 8's q-th workgroup
+// (q = w / 8) is member q % G of group (q / G) * 8 + x.  A bijection of [0, total): by construction on the whole multiples
+// of 8 G, identity on the tail and for G <= 1.  (bf_beamform_mfma.hip says when it is used.)
+__host__ __device__ inline uint32_t bf_xcd_grouped(uint32_t w, uint32_t total, uint32_t G)
+{
+    if (G <= 1u) return w;
+    const uint32_t full = total - total % (8u * G);
+    if (w >= full) return w;
+    const uint32_t x = w & 7u, q = w >> 3;
+    return ((q / G) * 8u + x) * G + q % G;
+}
+
 #ifdef DCS_PROBES
 #define BACC_KNOB(a, f) ((a).f)
 #else

@@ -77,6 +77,11 @@ int dcs_probe_reduce(const void *d_in, size_t bytes, uint64_t *checksum, float *
  * FLOP per launch = blocks * 4 * iters * 16 * (2048 or 4096). */
 int dcs_probe_mfma(int which, uint32_t blocks, uint32_t iters, float *d_out, void *stream);
 
+/* The coefficient-reuse beamformer's XCD-aware workgroup numbering (bf_kernels.h: bf_xcd_grouped), evaluated on the HOST:
+ * dispatch number w of a grid of `total` workgroups -> logical workgroup number, `group` consecutive logical workgroups per XCD.
+ * tests/test_host_abi.py checks that it is a bijection and that a group's members share w % 8. */
+uint32_t dcs_probe_xcd_grouped(uint32_t w, uint32_t total, uint32_t group);
+
 /* Device-to-device copy by the leanest kernel (one 16-byte load and store per thread, `per_thread` of them `stride_kib`
  * KiB apart when > 1; workgroups in address order): the mixed read + write rate the HBM system sustains, which the
  * coefficient-reuse beamformer at 16 beams (as many bytes in as out) is read against.  store_mode 0 plain, 1 nontemporal. */

@@ -11,6 +11,7 @@
 #include <cstring>
 #include <new>
 
+#include "../dc_sand_amd/csrc/bf_kernels.h" // bf_xcd_grouped (host-callable)
 #include "../dc_sand_amd/csrc/bf_math.h"
 
 namespace {
@@ -382,6 +383,8 @@ int dcs_probe_sincos(int which, const float *d_x, size_t n, float *d_sin, float 
     if (which < 0 || which > 4 || (n && (!d_x || !d_sin || !d_cos))) return DCS_ERR_INVALID_ARGUMENT;
     return (int)bf_launch_probe_sincos(which, d_x, n, d_sin, d_cos, as_stream(stream));
 }
+
+uint32_t dcs_probe_xcd_grouped(uint32_t w, uint32_t total, uint32_t group) { return bf_xcd_grouped(w, total, group); } // host only
 
 int dcs_probe_copy(const void *d_in, void *d_out, size_t bytes, int store_mode, int per_thread, void *stream)
 {

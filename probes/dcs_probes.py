@@ -24,6 +24,7 @@ SIGNATURES = [
     ("dcs_probe_mfma", c_int, [c_int, c_uint32, c_uint32, _VP, _VP]),
     ("dcs_probe_store_pattern", c_int, [_VP, c_uint32, c_uint32, c_uint32, c_uint32, c_int, c_int, c_int, c_uint32, _VP]),
     ("dcs_probe_set_knobs", c_int, [_VP, _VP]),
+    ("dcs_probe_xcd_grouped", c_uint32, [c_uint32, c_uint32, c_uint32]),
 ]
 
 # struct dcs_probe_knobs (include/dcs_probes.h), in order

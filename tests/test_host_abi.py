@@ -50,7 +50,7 @@ def test_product_library_exports_no_measurement_apparatus(dcs_lib):
     pexp = {l.split()[-1] for l in psyms.splitlines() if " T " in l}
     text = re.sub(r"/\*.*?\*/", "", (ROOT / "include" / "dcs_probes.h").read_text(), flags=re.S)
     declared_probes = set(re.findall(r"\b(dcs_probe_[a-z0-9_]+)\s*\(", text))
-    assert len(declared_probes) == 8 and declared_probes <= pexp
+    assert len(declared_probes) == 9 and declared_probes <= pexp
     assert "dcs_probe_set_knobs" in declared_probes and "dcs_probe_set_knobs" not in exported
     assert set(_declared_functions()) <= pexp  # the probes library is a superset build
 
@@ -91,6 +91,33 @@ def test_abi_3_structs_as_a_c_compiler_lays_them_out(dcs_lib, tmp_path):
     assert out[11] == "abi 3"
     # 49 entry points in ABI 2 + the three device-table stream ticks
     assert len(_declared_functions()) == 52
+
+
+def test_xcd_grouped_workgroup_numbering_is_a_bijection():
+    """The matrix-core beamformers renumber their workgroups so that the G workgroups sharing a channel's samples run on one
+    XCD (bf_kernels.h: bf_xcd_grouped, the very function the kernels call, evaluated on the host through the probes library):
+    for every grid size and group size tried it is a permutation of [0, total), the members of a whole group come from
+    dispatch numbers with equal w % 8 (one XCD) and consecutive w / 8 (one after the other), the eight XCDs' q-th groups are
+    eight NEIGHBOURING logical groups, and the tail that does not fill 8 G workgroups is left as dispatched."""
+    from probes import dcs_probes
+
+    f = dcs_probes.lib().dcs_probe_xcd_grouped
+    for G in (1, 2, 3, 4, 5, 16, 64):
+        for total in (1, 7, 8, 8 * G - 1, 8 * G, 8 * G + 1, 40 * G + 3, 4096, 4099, 16384 + 5 * G):
+            logical = np.array([f(w, total, G) for w in range(total)], dtype=np.int64)
+            assert np.array_equal(np.sort(logical), np.arange(total)), (G, total)
+            full = total - total % (8 * G)
+            assert np.array_equal(logical[full:], np.arange(full, total))
+            if G == 1:
+                assert np.array_equal(logical, np.arange(total))
+                continue
+            w_of = np.argsort(logical)  # logical number -> dispatch number
+            for grp in range(0, full // G, max(1, full // G // 50)):
+                ws = w_of[grp * G:(grp + 1) * G]
+                assert len(set(ws % 8)) == 1 and np.array_equal(ws // 8, ws[0] // 8 + np.arange(G)), (G, total, grp)
+            for q in range(0, full // (8 * G), max(1, full // (8 * G) // 20)):  # the XCDs' q-th groups: logical groups 8 q .. 8 q + 7
+                groups = sorted({int(logical[(q * G) * 8 + x]) // G for x in range(8)})
+                assert groups == list(range(8 * q, 8 * q + 8)), (G, total, q)
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
