@@ -273,7 +273,7 @@ DCS_HD void dcs_sincos_fast(const float x, float *fSin, float *fCos)
 // takes as they are --, high word:   n = 0: 0    1: 0x00008000 (cos)    2: 0x80008000 (both)    3: 0x80000000 (sin)
 // i.e. sin's sign = bit 1 of n, cos's = bit 1 of n + 1.  v_lshlrev_b32, v_alignbit_b32, v_lshlrev_b64, v_xor_b32: four
 // operations where round 2 had six (two shifts and two v_bitop3_b32 for the signs): +5 % on the VALU-issue-bound b16
-// generator (profiles/r03_fp16.md; the 64-bit shift issues like a 32-bit one).
+// generator (profiles/r03_fp16.md: 8.7 % fewer operations bought 5.0 %, so the 64-bit shift costs at most two issue slots).
 DCS_HD uint32_t dcs_quadrant_half2(const uint32_t p, const uint32_t q)
 {
     const uint32_t amt = q << 4; // bit 4 = n mod 2: rotate the halves by 16 when n is odd; bits 4-5 = n mod 4
