@@ -285,10 +285,13 @@ enum { kStaged = 0, kDirect = 1, kSplit = 2, kChain = 3 };
 // loads issued before this step's wait (1-4 % slower).
 constexpr int kChainWaves = 3;
 
-template <int FORM, bool FULL>
-__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(FORM == kSplit ? (FULL ? 3 : 2) : (FORM == kChain ? kChainWaves : (FULL || FORM == kStaged ? 4 : 3)))))
+// NW: waves per workgroup -- 4; 8 (kStaged, eight beam tiles per workgroup) is instantiated in the probes build only: an A/B
+// that measured no gain over four tiles (profiles/r03_fused.md)
+template <int FORM, bool FULL, int NW = 4>
+__global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(FORM == kSplit ? (FULL ? 3 : 2) : (FORM == kChain ? kChainWaves : (FULL || FORM == kStaged ? 4 : 3)))))
 bf_beamform_i8_kernel(const bf_bacc_args a)
 {
+    static_assert(NW == 4 || (NW == 8 && FORM == kStaged), "eight-wave workgroups exist for the staged form only");
     constexpr bool STAGED = FORM == kStaged, SPLIT = FORM == kSplit, CHAIN = FORM == kChain;
     extern __shared__ __attribute__((aligned(16))) char staged[]; // kStaged: the sample image (+ the coefficient exchange); kSplit: the partial sums
     uint32_t bid = BACC_LOGICAL_ID(a);
@@ -300,7 +303,7 @@ bf_beamform_i8_kernel(const bf_bacc_args a)
     const uint32_t c = bid / a.n_tgroups;
     // beam tiles per workgroup, sample blocks per round (kSplit: one tile, every wave takes every block)
     const uint32_t nbt_log2 = SPLIT || CHAIN ? 0u : a.nbt_log2;
-    const uint32_t nbt = 1u << nbt_log2, tpr = SPLIT ? 1u : 4u >> nbt_log2;
+    const uint32_t nbt = 1u << nbt_log2, tpr = SPLIT ? 1u : (uint32_t)NW >> nbt_log2;
     const uint32_t bt = SPLIT ? 0u : wave & (nbt - 1u), slot = SPLIT ? 0u : wave >> nbt_log2;
     const uint32_t kc = SPLIT || CHAIN ? wave : 0u; // the 64-antenna chunk whose coefficients this wave makes (and, kSplit, contracts)
     const uint32_t lm = lane & 15u, lg = lane >> 4;
@@ -316,7 +319,7 @@ bf_beamform_i8_kernel(const bf_bacc_args a)
         typedef const __attribute__((address_space(1))) void glb_void;
         const uint32_t bytes = (tt1 - tt0) * a.A * 32u; // a multiple of 32
         const char *src = reinterpret_cast<const char *>(a.ant) + ((uint64_t)c * a.nT16 + tt0) * a.A * 32u;
-        for (uint32_t k = wave; k * 1024u < bytes; k += 4u) // a piece that overhangs the end re-reads the last 16 bytes
+        for (uint32_t k = wave; k * 1024u < bytes; k += (uint32_t)NW) // a piece that overhangs the end re-reads the last 16 bytes
             __builtin_amdgcn_global_load_lds((glb_void *)(src + min(k * 1024u + lane * 16u, bytes - 16u)), (lds_void *)(staged + k * 1024u),
                                              16, 0, 0);
     }
@@ -773,16 +776,22 @@ hipError_t bf_launch_beamform_acc(const bf_bacc_args &a_in, hipStream_t stream)
     // more than 64 antennas, int8 form: one beam tile per workgroup; kChain (the product's form) or, probes build only, kSplit
     const bool wide = !chain && a.A > 64u;
     const bool split = wide && BACC_KNOB(a, unstaged) != 0u; // kSplit (round 2): every wave takes every block, partial sums meet in LDS
+    const bool staged_form = !chain && a.A <= 64u && !BACC_KNOB(a, unstaged); // at most 16 blocks (32 KiB of LDS) per workgroup
     int nbt = wide ? 1 : (a.B > 32u ? 4 : (a.B > 16u ? 2 : 1));
+#ifdef DCS_PROBES
+    // A/B: beam tiles per workgroup.  1 / 2 / 4 / 8 (eight-wave workgroups) at 64 x 256 x 4096 x 256: 552 / 502 / 396 / 399 us --
+    // four is where the samples' re-staging stops mattering (profiles/r03_fused.md); eight exists in the probes build only
+    if (staged_form && (a.nbt_force == 1u || a.nbt_force == 2u || a.nbt_force == 4u || a.nbt_force == 8u)) nbt = (int)a.nbt_force;
+#endif
+    const uint32_t nw = nbt == 8 ? 8u : 4u; // waves per workgroup
     while (chain && nbt > 1 && bacc_lds_bytes(nbt, a.A) > 26u * 1024u) nbt >>= 1;
     const size_t lds = chain ? bacc_lds_bytes(nbt, a.A) : 0u;
-    a.nbt_log2 = nbt == 4 ? 2u : (nbt == 2 ? 1u : 0u);
+    a.nbt_log2 = nbt == 8 ? 3u : (nbt == 4 ? 2u : (nbt == 2 ? 1u : 0u));
     a.n_bgroups = (a.B + 16u * (uint32_t)nbt - 1u) / (16u * (uint32_t)nbt);
     // 16-sample blocks per workgroup: whole rounds of 4 / nbt blocks, at most max_rounds (the coefficients are
     // generated once per workgroup; but a launch of only a few thousand long-lived workgroups ends with most of the
     // chip idle behind the last ones), fewer while that leaves the chip under 4096 workgroups
-    const uint32_t tpr = split ? 1u : 4u / (uint32_t)nbt; // (K-split: every wave takes every block)
-    const bool staged_form = !chain && a.A <= 64u && !BACC_KNOB(a, unstaged); // at most 16 blocks (32 KiB of LDS) per workgroup
+    const uint32_t tpr = split ? 1u : nw / (uint32_t)nbt; // (K-split: every wave takes every block)
     const uint32_t max_rounds = BACC_KNOB(a, max_rounds) ? BACC_KNOB(a, max_rounds) : (chain ? 16u : (staged_form || wide ? 16u / tpr : 32u));
     uint32_t tiles = (a.nT16 + tpr - 1u) / tpr * tpr;
     if (tiles > max_rounds * tpr) { // several workgroups per (channel, beam group): equal shares (17 blocks are 9 + 8, not 16 + 1)
@@ -791,7 +800,7 @@ hipError_t bf_launch_beamform_acc(const bf_bacc_args &a_in, hipStream_t stream)
     }
     // (the int8 form makes its coefficients once per wave -- half its arithmetic at 16 blocks -- so it only splits
     // further while the chip, which holds 1280 of its workgroups, would not even be filled once)
-    const uint64_t enough = chain ? 4096u : 1280u;
+    const uint64_t enough = chain ? 4096u : (nw == 8u ? 640u : 1280u);
     while (tiles > tpr && (uint64_t)a.C * a.n_bgroups * ((a.nT16 + tiles - 1u) / tiles) < enough) tiles = ((tiles / tpr + 1u) / 2u) * tpr;
     a.tiles_per_wg = tiles;
     a.n_tgroups = (a.nT16 + tiles - 1u) / tiles;
@@ -799,7 +808,7 @@ hipError_t bf_launch_beamform_acc(const bf_bacc_args &a_in, hipStream_t stream)
     a.xcd_group = wide ? a.n_bgroups : (!chain && a.n_bgroups >= 16u ? a.n_bgroups : 1u);
     const uint64_t blocks = (uint64_t)a.C * a.n_bgroups * a.n_tgroups;
     if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
-    const dim3 grid((uint32_t)blocks), block(kBlock);
+    const dim3 grid((uint32_t)blocks), block(64u * nw);
     if (chain) {
         if (nbt == 4)
             hipLaunchKernelGGL(bf_beamform_acc_kernel<4>, grid, block, lds, stream, a);
@@ -809,13 +818,21 @@ hipError_t bf_launch_beamform_acc(const bf_bacc_args &a_in, hipStream_t stream)
             hipLaunchKernelGGL(bf_beamform_acc_kernel<1>, grid, block, lds, stream, a);
     } else if (staged_form) {
         size_t stage_bytes = ((size_t)a.tiles_per_wg * a.A * 32u + 1023u) / 1024u * 1024u;
-        if (nbt < 4 && !BACC_KNOB(a, no_share)) { // waves that own the same tile share the making of its coefficients
+        if (tpr > 1u && !BACC_KNOB(a, no_share)) { // waves that own the same tile share the making of its coefficients
             a.share_off = (uint32_t)stage_bytes;
             stage_bytes += (size_t)nbt * 4u * 6u * 64u * sizeof(uint32_t);
         }
 #ifdef DCS_PROBES
         if (a.wg_per_cu >= 1u && a.wg_per_cu <= 5u && stage_bytes < 160u * 1024u / a.wg_per_cu) // residency cap: unused LDS
             stage_bytes = (160u * 1024u / a.wg_per_cu) & ~1023u;
+#endif
+#ifdef DCS_PROBES
+        if (nw == 8u) {
+            if (a.A == 64u)
+                hipLaunchKernelGGL((bf_beamform_i8_kernel<kStaged, true, 8>), grid, block, stage_bytes, stream, a);
+            else
+                hipLaunchKernelGGL((bf_beamform_i8_kernel<kStaged, false, 8>), grid, block, stage_bytes, stream, a);
+        } else
 #endif
         if (a.A == 64u)
             hipLaunchKernelGGL((bf_beamform_i8_kernel<kStaged, true>), grid, block, stage_bytes, stream, a);

@@ -1608,7 +1608,9 @@ def test_autotune_measures_a_large_shape_once(gpu, oracle):
                                        (64, 32, 3, 112), (64, 24, 2, 272), (64, 16, 2, 592), (48, 16, 3, 48), (64, 64, 2, 272),
                                        (256, 64, 2, 272), (100, 20, 3, 112), (256, 16, 1, 1600), (65, 16, 2, 48),
                                        # enough workgroups for the XCD-grouped numbering to leave its identity tail (> 8 x the sharers):
-                                       (64, 1024, 9, 32), (130, 20, 9, 32), (256, 64, 9, 16), (192, 48, 11, 48)])
+                                       (64, 1024, 9, 32), (130, 20, 9, 32), (256, 64, 9, 16), (192, 48, 11, 48),
+                                       # more than 64 beams at <= 64 antennas (several beam groups per channel, ragged last group)
+                                       (64, 128, 3, 64), (48, 200, 2, 48), (64, 72, 2, 32), (33, 129, 2, 16), (64, 256, 2, 272)])
 def test_beamform_accumulated_on_the_matrix_cores(gpu, oracle, A, B, C, nt, math_mode):
     """dcs_bf_beamform_accumulated: the coefficients of ONE time applied to nt samples as two real contractions over the
     antennas on the matrix cores, against the verifier's beamformer with the coefficient held
