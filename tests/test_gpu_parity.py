@@ -781,6 +781,20 @@ def test_config4_one_rank_shard_at_full_size_every_element(gpu, oracle, probes, 
     buf.free()
 
 
+@pytest.mark.parametrize("script,args", [("steering_coefficients.py", ["16", "24", "512"]), ("streaming_ticks.py", ["16", "64", "2048", "256", "20"])])
+def test_examples_run_and_verify_themselves(gpu, script, args):
+    """examples/: the pycuda-shaped host pattern and the config-5 stream with device tables, on small shapes; each verifies
+    its own output against the oracle and exits 0."""
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    res = subprocess.run([sys.executable, str(root / "examples" / script), *args], capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-1500:] + res.stderr[-1500:]
+    assert "max ULP distance to the CPU verifier" in res.stdout
+
+
 def test_cpp_host_against_c_abi(gpu):
     """The reference's harness is C++: tests/cpp/run_beamformer_tests.cpp is the
     runBeamformerTests executable written against the C-ABI (plain g++, no hipcc

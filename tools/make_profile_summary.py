@@ -100,7 +100,7 @@ bench.py first lets the library measure its launch geometry (untimed; separate k
 (`__amd_rocclr_fillBufferAligned`, ~2.8 ms each = 6.1 TB/s) to bring the device out of idle; the first few generator launches are
 still 3-10 % slower than steady state and fall in the W = 10 warm-up steps.  The event-based `kernel_ms`, the per-dispatch
 trace of the same launches and the `--stats` average agree within 1 % (the event span also holds the 5-us slice gather and the gaps between launches, which grow a little under the profiler).  HBM traffic equals the algorithmic bytes: every store is a whole-line write,
-nothing is re-read.  Box-to-box spread of `value`: 894-937 Gcoeff/s over fifteen boxes in round 2 (thirteen of them 915-937); the bench lines of round 3's boxes: 913.1, 928.3, 930.0.
+nothing is re-read.  Box-to-box spread of `value`: 894-937 Gcoeff/s over fifteen boxes in round 2 (thirteen of them 915-937); the bench lines of round 3's boxes: 913.1, 918.1, 928.3, 930.0, 930.4, 930.8.
 """
 # (a section appended by hand below a "## A minute of back-to-back steps" heading survives regeneration)
 try:
