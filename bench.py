@@ -795,13 +795,27 @@ def main():
             check = spot_check()  # before anything else rewrites the output buffer
         samples = []
         if N == 1 and not args.no_extras:
-            result["also_measured"] = extras(gen, bp, out, out_bytes, sh, device, args.sustain_seconds, samples)
+            # the side measurements must not be able to take the headline line down with them: a failure there is REPORTED
+            # (also_measured.error / extras_vs_oracle_all_ok), the line is still printed
+            try:
+                result["also_measured"] = extras(gen, bp, out, out_bytes, sh, device, args.sustain_seconds, samples)
+            except Exception as e:  # noqa: BLE001
+                import traceback
+
+                traceback.print_exc()
+                result["also_measured"] = {"error": f"{type(e).__name__}: {e}"}
         if N == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(bp, np.ascontiguousarray(table_host), args.cpu_seconds)
             if samples:
-                chk = check_extras_against_oracle(bp, np.ascontiguousarray(table_host), samples)
+                try:
+                    chk = check_extras_against_oracle(bp, np.ascontiguousarray(table_host), samples)
+                except Exception as e:  # noqa: BLE001
+                    chk = [{"item": "check_extras_against_oracle", "ok": False, "error": f"{type(e).__name__}: {e}"}]
                 result["cpu_baseline"]["extras_vs_oracle"] = chk
-                assert all(c["ok"] for c in chk), [c for c in chk if not c["ok"]]
+                result["cpu_baseline"]["extras_vs_oracle_all_ok"] = bool(all(c["ok"] for c in chk))
+                for c in chk:
+                    if not c["ok"]:
+                        print(f"bench.py: side measurement differs from the oracle: {c}", file=sys.stderr)
             result["cpu_baseline"]["gpu_vs_oracle_spot_check"] = {"max_ulp": check[0], "over_1ulp": check[1],
                                                                   "max_ulp_float_libm_reading": check[2],
                                                                   "sample": "first 4 channels of the last timed step"}

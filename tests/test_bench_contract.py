@@ -81,7 +81,8 @@ def test_single_gpu_line_with_cpu_baseline():
     assert c["gpu_vs_oracle_spot_check"]["over_1ulp"] == 0
     # every side measurement's last output is checked against the oracle too (in the cpu_baseline leg)
     xs = c["extras_vs_oracle"]
-    assert len(xs) >= 9 and all(x["ok"] for x in xs), [x for x in xs if not x["ok"]]
+    assert len(xs) >= 9 and all(x["ok"] for x in xs) and c["extras_vs_oracle_all_ok"] is True, [x for x in xs if not x["ok"]]
+    assert "error" not in am
     assert any("device memory" in x["item"] for x in xs) and any(x["item"].startswith("beamform_accumulated 256x") for x in xs)
     assert c["beamform_accumulated"]["value"] > 0 and c["beamform_accumulated"]["cores"] == 1
 
