@@ -129,6 +129,15 @@ def test_streaming_step_with_the_table_gathered_in_graph():
     assert "dcs_bf_stream_tick_dt_from_global" in d["config"]["kernel"] and d["rccl_world_size"] == 1
 
 
+def test_two_ranks_streaming_from_the_broadcast_buffer_over_gloo():
+    """configs[3] + configs[4] with a REAL inter-process broadcast (gloo; both ranks on GPU 0: a rehearsal): every step a graph
+    replay whose table is the buffer the broadcast has just filled, each rank gathering its own beam slice in-graph and
+    checking its slab against the oracle; started by bench.py itself (no launcher)."""
+    d = _run(["--gpus", "2", "--backend", "gloo", "--shared-device", "--streaming", "--check-all-ranks", "--no-cpu-baseline", "--no-extras"])
+    _common(d, n_gpus=2)
+    assert "dcs_bf_stream_tick_dt_from_global" in d["config"]["kernel"] and "gloo" in d["config"]["collective"]
+
+
 def test_named_config_reaches_the_workload_field():
     d = _run(["--config", "cfg4", "--no-cpu-baseline", "--no-extras"])
     assert d["config"]["workload"].startswith("cfg4 (shape overridden)") and "configs[3]" in d["config"]["named_config"]
