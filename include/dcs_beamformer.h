@@ -257,8 +257,9 @@ int dcs_bf_beamform_accumulated_dt(dcs_bf_context *ctx, float dt_coeff, uint32_t
  * geometry": per launch the library looks at the tiles per row, the workgroups the launch makes and
  * its bytes -- fp32: 1 tile x 12 channels per workgroup and at most 6 workgroups per CU when there is
  * plenty of work (no limit for launches of 256 MiB - 2 GiB), 10 channels without limit for rows of >= 2048 tiles,
- * 2 tiles x 16 channels for launch-bound tensors of <= 32 MiB; fp16: 128 channels, fewer while the chip would be left under 2048
- * workgroups; no residency limit when every workgroup is resident at once).  Two forms of the
+ * 2 tiles x 16 channels for launch-bound tensors of <= 32 MiB; launches of >= 2 GiB (terms table): fp32 8 channels x 6 workgroups
+ * per CU, fp16 48 x 5 (20 x 6 with the b16 arithmetic form); smaller fp16 launches 128 channels, fewer while the chip would be left
+ * under 2048 workgroups; no residency limit when every workgroup is resident at once).  Two forms of the
  * MULTIPLE_CHANNELS_AND_TIMESTAMPS generator exist and give identical bits:
  *   "tiled": a workgroup (4 waves) keeps its pairs' terms in registers and walks chan_per_block
  *           channels, tiles_per_block 1-KiB tiles wide.  The terms (one fp64 chain per pair and time
