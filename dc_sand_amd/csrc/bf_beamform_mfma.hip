@@ -291,7 +291,7 @@ template <int FORM, bool FULL, int NW = 4>
 __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(FORM == kSplit ? (FULL ? 3 : 2) : (FORM == kChain ? kChainWaves : (FULL || FORM == kStaged ? 4 : 3)))))
 bf_beamform_i8_kernel(const bf_bacc_args a)
 {
-    static_assert(NW == 4 || (NW == 8 && FORM == kStaged), "eight-wave workgroups exist for the staged form only");
+    static_assert(NW == 4 || ((NW == 8 || NW == 16) && FORM == kStaged), "8- and 16-wave workgroups exist for the staged form only");
     constexpr bool STAGED = FORM == kStaged, SPLIT = FORM == kSplit, CHAIN = FORM == kChain;
     extern __shared__ __attribute__((aligned(16))) char staged[]; // kStaged: the sample image (+ the coefficient exchange); kSplit: the partial sums
     uint32_t bid = BACC_LOGICAL_ID(a);
@@ -783,7 +783,10 @@ hipError_t bf_launch_beamform_acc(const bf_bacc_args &a_in, hipStream_t stream)
     // four is where the samples' re-staging stops mattering (profiles/r03_fused.md); eight exists in the probes build only
     if (staged_form && (a.nbt_force == 1u || a.nbt_force == 2u || a.nbt_force == 4u || a.nbt_force == 8u)) nbt = (int)a.nbt_force;
 #endif
-    const uint32_t nw = nbt == 8 ? 8u : 4u; // waves per workgroup
+    uint32_t nw = nbt == 8 ? 8u : 4u; // waves per workgroup
+#ifdef DCS_PROBES
+    if (staged_form && (a.nw_force == 8u || a.nw_force == 16u) && a.nw_force >= (uint32_t)nbt) nw = a.nw_force; // A/B: waves per workgroup
+#endif
     while (chain && nbt > 1 && bacc_lds_bytes(nbt, a.A) > 26u * 1024u) nbt >>= 1;
     const size_t lds = chain ? bacc_lds_bytes(nbt, a.A) : 0u;
     a.nbt_log2 = nbt == 8 ? 3u : (nbt == 4 ? 2u : (nbt == 2 ? 1u : 0u));
@@ -800,7 +803,7 @@ hipError_t bf_launch_beamform_acc(const bf_bacc_args &a_in, hipStream_t stream)
     }
     // (the int8 form makes its coefficients once per wave -- half its arithmetic at 16 blocks -- so it only splits
     // further while the chip, which holds 1280 of its workgroups, would not even be filled once)
-    const uint64_t enough = chain ? 4096u : (nw == 8u ? 640u : 1280u);
+    const uint64_t enough = chain ? 4096u : 5120u / nw;
     while (tiles > tpr && (uint64_t)a.C * a.n_bgroups * ((a.nT16 + tiles - 1u) / tiles) < enough) tiles = ((tiles / tpr + 1u) / 2u) * tpr;
     a.tiles_per_wg = tiles;
     a.n_tgroups = (a.nT16 + tiles - 1u) / tiles;
@@ -832,6 +835,11 @@ hipError_t bf_launch_beamform_acc(const bf_bacc_args &a_in, hipStream_t stream)
                 hipLaunchKernelGGL((bf_beamform_i8_kernel<kStaged, true, 8>), grid, block, stage_bytes, stream, a);
             else
                 hipLaunchKernelGGL((bf_beamform_i8_kernel<kStaged, false, 8>), grid, block, stage_bytes, stream, a);
+        } else if (nw == 16u) {
+            if (a.A == 64u)
+                hipLaunchKernelGGL((bf_beamform_i8_kernel<kStaged, true, 16>), grid, block, stage_bytes, stream, a);
+            else
+                hipLaunchKernelGGL((bf_beamform_i8_kernel<kStaged, false, 16>), grid, block, stage_bytes, stream, a);
         } else
 #endif
         if (a.A == 64u)

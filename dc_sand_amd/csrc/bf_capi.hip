@@ -1209,6 +1209,7 @@ int beamform_acc_impl(dcs_bf_context *c, const dt_source &src, uint32_t nt, cons
     a.wg_per_cu = knob(c->probe.bacc_wg_per_cu, "DCS_BACC_WPC");
     a.order = knob(c->probe.bacc_order, "DCS_BACC_ORDER");
     a.nbt_force = knob(c->probe.bacc_nbt, "DCS_BACC_NBT");
+    a.nw_force = knob(c->probe.bacc_waves, "DCS_BACC_WAVES");
 #endif
     return (int)bf_launch_beamform_acc(a, s);
 }

@@ -149,7 +149,8 @@ struct bf_bacc_args {
     uint32_t wg_per_cu;    // staged int8 form: at most this many workgroups resident per CU (0 = as many as fit)
     uint32_t unstaged;     // int8 form, <= 64 antennas: operands straight from global memory instead of through LDS
     uint32_t order;        // workgroup numbering: 0 = the launcher's choice, 1 = as dispatched (round 2), 2 = a contiguous eighth per XCD, 3 = sharers always grouped
-    uint32_t nbt_force;    // staged form: beam tiles per workgroup (1, 2, 4; 0 = the launcher's choice)
+    uint32_t nbt_force;    // staged form: beam tiles per workgroup (1, 2, 4, 8; 0 = the launcher's choice)
+    uint32_t nw_force;     // staged form: waves per workgroup (8, 16; 0 = the launcher's choice)
     uint32_t probe;        // 1 = stores only, 2 = loads and stores without arithmetic, 3 = stores without coefficients either,
                            // 4 = as 3 with one contiguous KiB per store instruction
 #endif

@@ -39,6 +39,7 @@ struct dcs_probe_knobs {
     int32_t bacc_order;     /* workgroup numbering: 0 = the product's choice, 1 = as dispatched (round 2), 2 = one contiguous
                              * eighth of the order per XCD, 3 = the workgroups sharing a channel's samples always on one XCD */
     int32_t bacc_nbt;       /* staged form: beam tiles per workgroup (1, 2, 4, or 8 with eight-wave workgroups; 0 = the launcher's choice) */
+    int32_t bacc_waves;     /* staged form: waves per workgroup (8 or 16; 0 = the launcher's choice, 4) */
 };
 int dcs_probe_set_knobs(dcs_bf_context *ctx, const struct dcs_probe_knobs *k);
 

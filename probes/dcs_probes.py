@@ -29,7 +29,7 @@ SIGNATURES = [
 
 # struct dcs_probe_knobs (include/dcs_probes.h), in order
 KNOB_FIELDS = ("nomath", "pace", "fail_at_step", "bacc_probe", "bacc_rounds", "bacc_no_share", "bacc_plain", "bacc_wg_per_cu",
-               "bacc_unstaged", "bacc_order", "bacc_nbt")
+               "bacc_unstaged", "bacc_order", "bacc_nbt", "bacc_waves")
 
 _LIB = None
 
