@@ -280,10 +280,11 @@ __device__ __forceinline__ uint32_t fixed_word(float w)
 //       recombination arithmetic, and a result that is one fp32 rounding closer to the exact sum.
 // FULL: nr_stations is a multiple of 64 (no antenna masks, immediate load offsets).
 enum { kStaged = 0, kDirect = 1, kSplit = 2, kChain = 3 };
-// kChain is allocated for 3 waves per SIMD (147 VGPRs) and walks with TWO sample buffers.  Tried and not kept (profiles/r03_fused.md):
-// 4 waves per SIMD (<= 128 registers: 4 spills to scratch), a third sample buffer (168 registers, 2 spills), and the next step's
-// loads issued before this step's wait (1-4 % slower).
-constexpr int kChainWaves = 3;
+// kChain is allocated for 4 waves per SIMD (127 VGPRs, no scratch: the coefficient digits go straight to LDS as they are made,
+// and the results are recombined and stored one register at a time) and walks with TWO sample buffers.  It measures the same at 3
+// waves (the kernel is issue-bound: profiles/r03_fused.md); tried and not kept: a third sample buffer (168 registers, 2 spills), the
+// next step's loads issued before this step's wait (1-4 % slower).
+constexpr int kChainWaves = 4;
 
 // NW: waves per workgroup -- 4; 8 (kStaged, eight beam tiles per workgroup) is instantiated in the probes build only: an A/B
 // that measured no gain over four tiles (profiles/r03_fused.md)
@@ -393,8 +394,14 @@ bf_beamform_i8_kernel(const bf_bacc_args a)
                     const floatx2 k4[4] = {kp[4 * q], kp[4 * q + 1], kp[4 * q + 2], kp[4 * q + 3]};
                     uint32_t nr[3], ni[3];
                     four(gen, std::false_type{}, q, k4, nr, ni);
+                    if constexpr (CHAIN) { // straight to the LDS image (component q of the chunk's six operands): the 24 registers are never held
+                        uint32_t *cw = reinterpret_cast<uint32_t *>(staged) + (kc * 6u * 64u + lane) * 4u + q;
 #pragma unroll
-                    for (int d = 0; d < 3; d++) wre[d][q] = (int)nr[d], wim[d][q] = (int)ni[d];
+                        for (int d = 0; d < 3; d++) cw[(uint32_t)d * 256u] = beam_live ? nr[d] : 0u, cw[(3u + (uint32_t)d) * 256u] = beam_live ? ni[d] : 0u;
+                    } else {
+#pragma unroll
+                        for (int d = 0; d < 3; d++) wre[d][q] = (int)nr[d], wim[d][q] = (int)ni[d];
+                    }
                 }
             } else { // the new register enters at the top while the others, and the loaded terms, move down -- no
                      // register is indexed by a loop variable
@@ -403,16 +410,22 @@ bf_beamform_i8_kernel(const bf_bacc_args a)
                     const floatx2 k4[4] = {kp[0], kp[1], kp[2], kp[3]};
                     uint32_t nr[3], ni[3];
                     four(gen, std::true_type{}, q, k4, nr, ni);
+                    if constexpr (CHAIN) {
+                        uint32_t *cw = reinterpret_cast<uint32_t *>(staged) + (kc * 6u * 64u + lane) * 4u + q;
 #pragma unroll
-                    for (int d = 0; d < 3; d++) {
-                        wre[d] = intx4{wre[d][1], wre[d][2], wre[d][3], (int)nr[d]};
-                        wim[d] = intx4{wim[d][1], wim[d][2], wim[d][3], (int)ni[d]};
+                        for (int d = 0; d < 3; d++) cw[(uint32_t)d * 256u] = beam_live ? nr[d] : 0u, cw[(3u + (uint32_t)d) * 256u] = beam_live ? ni[d] : 0u;
+                    } else {
+#pragma unroll
+                        for (int d = 0; d < 3; d++) {
+                            wre[d] = intx4{wre[d][1], wre[d][2], wre[d][3], (int)nr[d]};
+                            wim[d] = intx4{wim[d][1], wim[d][2], wim[d][3], (int)ni[d]};
+                        }
                     }
 #pragma unroll
                     for (uint32_t z = 0; z < 12; z++) kp[z] = kp[z + 4];
                 }
             }
-            if (!beam_live) { // beams beyond nr_beams: zero coefficients (their results are not stored either)
+            if (!CHAIN && !beam_live) { // beams beyond nr_beams: zero coefficients (their results are not stored either)
 #pragma unroll
                 for (int d = 0; d < 3; d++) wre[d] = wim[d] = intx4{0, 0, 0, 0};
             }
@@ -676,10 +689,7 @@ bf_beamform_i8_kernel(const bf_bacc_args a)
         // ---- the coefficients of this wave's chunk to LDS: [chunk][operand: re d1, d2, d3, im d1, d2, d3][lane] x 16 bytes
         intx4 *coef = reinterpret_cast<intx4 *>(staged);
         uint32_t *nanw = reinterpret_cast<uint32_t *>(staged + 4u * 6u * 64u * 16u); // [chunk][re, im]
-        if (has_chunk) {
-#pragma unroll
-            for (int d = 0; d < 3; d++) coef[(kc * 6u + (uint32_t)d) * 64u + lane] = wre[d], coef[(kc * 6u + 3u + (uint32_t)d) * 64u + lane] = wim[d];
-        }
+        // (make_coefficients has written this wave's chunk: operand o of chunk k at coef[(k * 6 + o) * 64 + lane])
         if (lane == 0u) nanw[2u * wave] = has_chunk ? nan_re : 0u, nanw[2u * wave + 1u] = has_chunk ? nan_im : 0u;
         __syncthreads(); // the kernel's only barrier
         if (idle) return;
@@ -708,21 +718,25 @@ bf_beamform_i8_kernel(const bf_bacc_args a)
                 }
 #pragma unroll
                 for (int half = 0; half < 2; half++) { // re planes (v = 0, 2), then im planes (v = 1, 3)
-                    intx4 w[3];
 #pragma unroll
-                    for (int d = 0; d < 3; d++) w[d] = coef[(chunk * 6u + 3u * (uint32_t)half + (uint32_t)d) * 64u + lane];
+                    for (int d = 0; d < 3; d++) {
+                        const intx4 w = coef[(chunk * 6u + 3u * (uint32_t)half + (uint32_t)d) * 64u + lane];
 #pragma unroll
-                    for (int v = half; v < 4; v += 2)
-#pragma unroll
-                        for (int d = 0; d < 3; d++) acc[v][d] = __builtin_amdgcn_mfma_i32_16x16x64_i8(w[d], x[v], acc[v][d], 0, 0, 0);
+                        for (int v = half; v < 4; v += 2) acc[v][d] = __builtin_amdgcn_mfma_i32_16x16x64_i8(w, x[v], acc[v][d], 0, 0, 0);
+                    }
                 }
                 if (chunk + 1u == n_chunks) { // all antennas in: digits d1 = acc[v][0], d2 = acc[v][1], d3 = acc[v][2]
-                    floatx4 f[4];
+                    // one result register (four beams' sixteen bytes) at a time: recombined, scaled, stored -- the sixteen floats
+                    // are never all alive beside the accumulators
 #pragma unroll
-                    for (int v = 0; v < 4; v++)
+                    for (int r = 0; r < 4; r++) {
+                        floatx4 o;
 #pragma unroll
-                        for (int r = 0; r < 4; r++) f[v][r] = fmaf((float)acc[v][0][r], 65536.0f, (float)(acc[v][1][r] * 256 + acc[v][2][r]));
-                    finish(whole, blk, f);
+                        for (int v = 0; v < 4; v++) o[v] = fmaf((float)acc[v][0][r], 65536.0f, (float)(acc[v][1][r] * 256 + acc[v][2][r])) * inv;
+                        if (nan_re | nan_im) poison(r, o);
+                        if (decltype(whole)::value || bb + 4u * (uint32_t)r < a.B) store(out_of(blk, r), o);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                     chunk = 0u, blk += 2u;
                 } else {
                     chunk++;
