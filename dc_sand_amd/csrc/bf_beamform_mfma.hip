@@ -809,7 +809,10 @@ hipError_t bf_launch_beamform_acc(const bf_bacc_args &a_in, hipStream_t stream)
     // generated once per workgroup; but a launch of only a few thousand long-lived workgroups ends with most of the
     // chip idle behind the last ones), fewer while that leaves the chip under 4096 workgroups
     const uint32_t tpr = split ? 1u : nw / (uint32_t)nbt; // (K-split: every wave takes every block)
-    const uint32_t max_rounds = BACC_KNOB(a, max_rounds) ? BACC_KNOB(a, max_rounds) : (chain ? 16u : (staged_form || wide ? 16u / tpr : 32u));
+    // (64 beams exactly fill one four-tile workgroup per channel: there EIGHT blocks per workgroup measured 3-5 % faster than
+    // sixteen on four shapes, while from 128 beams on eight or twelve blocks cost 3-7 %: profiles/r03_fused.md)
+    const uint32_t blocks_cap = staged_form && nbt == 4 && a.n_bgroups == 1u ? 8u : 16u;
+    const uint32_t max_rounds = BACC_KNOB(a, max_rounds) ? BACC_KNOB(a, max_rounds) : (chain ? 16u : (staged_form || wide ? blocks_cap / tpr : 32u));
     uint32_t tiles = (a.nT16 + tpr - 1u) / tpr * tpr;
     if (tiles > max_rounds * tpr) { // several workgroups per (channel, beam group): equal shares (17 blocks are 9 + 8, not 16 + 1)
         const uint32_t parts = (a.nT16 + max_rounds * tpr - 1u) / (max_rounds * tpr);
