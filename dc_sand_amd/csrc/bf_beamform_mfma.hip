@@ -70,6 +70,7 @@ __device__ __forceinline__ uint32_t xcd_grouped(uint32_t w, uint32_t total, uint
 __device__ __forceinline__ uint32_t probe_order(uint32_t order, uint32_t w, uint32_t total, uint32_t G, uint32_t n_sharers)
 {
     if (order == 1u) return w;
+    if (order >= 16u && order < 24u) return (w + (order - 16u)) % total; // 16 + r: as dispatched, rotated by r (XCD <-> channel affinity probe)
     if (order == 2u) {
         const uint32_t per = total >> 3, rem = total & 7u, x = w & 7u, q = w >> 3;
         return x * per + min(x, rem) + q;
